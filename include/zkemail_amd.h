@@ -1,0 +1,244 @@
+/*
+ * zkemail_amd.h — C-ABI of the MI355X-native batched email-verification engine.
+ *
+ * This is the drop-in boundary for zkemail_core's two public functions
+ *
+ *     pub fn verify_email(email: &Email) -> EmailVerifierOutput             (core/src/circuits.rs:9)
+ *     pub fn verify_email_with_regex(input: &EmailWithRegex)
+ *                                   -> EmailWithRegexVerifierOutput         (core/src/circuits.rs:31)
+ *
+ * The reference has no FFI of its own; these entry points are what a
+ * Rust `-sys` shim for that path binds (INTEGRATION.md shows the `extern "C"` block).
+ * Plain pointers and sizes only; no C++ or torch types.
+ *
+ * All multi-byte integers are host-endian (little-endian on the target).  Offsets
+ * arrays are CSR style: entry i spans blob[off[i] .. off[i+1]).
+ *
+ * Failure model.  The reference panics (process abort under its release profile,
+ * Cargo.toml:35).  A batch engine must not abort a batch, so every email gets a
+ * `status` naming the reference panic site that would have fired.  The C++ mirror in
+ * include/zkemail_core.hpp re-raises them to keep drop-in semantics.
+ */
+#ifndef ZKEMAIL_AMD_H
+#define ZKEMAIL_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ status codes */
+/* One per reference panic site. */
+enum {
+  ZKE_OK                  = 0,
+  ZKE_PARSE_FAIL          = 1,  /* mailparse::parse_mail(..).unwrap()            core/src/email.rs:26 */
+  ZKE_KEY_DECODE_FAIL     = 2,  /* DkimPublicKey::try_from_bytes(..).unwrap()    core/src/email.rs:29 */
+  ZKE_DKIM_ERROR          = 3,  /* verify_email_with_key(..).unwrap()            core/src/email.rs:33 */
+  ZKE_DKIM_NOT_PASS       = 4,  /* assert!(verified)                             core/src/circuits.rs:13 */
+  ZKE_EXTERNAL_INPUT_NULL = 5,  /* .expect("Value cannot be null")               core/src/circuits.rs:24 */
+  ZKE_CANON_FAIL          = 6,  /* canonicalize_signed_email(..).unwrap()        core/src/circuits.rs:35 */
+  ZKE_DFA_DECODE_FAIL     = 7,  /* dense::DFA::from_bytes(..).unwrap()           core/src/regex.rs:32-33 */
+  ZKE_HEADER_REGEX_FAIL   = 8,  /* assert!(verified) on header parts             core/src/circuits.rs:45 */
+  ZKE_BODY_REGEX_FAIL     = 9,  /* assert!(verified) on body parts               core/src/circuits.rs:54 */
+  ZKE_UNSUPPORTED         = 10  /* input is outside what this engine implements; never a silent mis-verify */
+};
+
+/* `detail` sub-codes.  For ZKE_DKIM_NOT_PASS they mirror cfdkim's DKIMError of the
+ * last signature tried (the text after "fail (" in DKIMResult::with_detail()). */
+enum {
+  ZKE_D_NONE                 = 0,
+  ZKE_D_NEUTRAL              = 1,  /* no DKIM-Signature with d= == from_domain was tried */
+  ZKE_D_SIG_SYNTAX           = 2,  /* tag-list did not parse */
+  ZKE_D_MISSING_TAG          = 3,  /* one of v a b bh d h s absent */
+  ZKE_D_INCOMPATIBLE_VERSION = 4,  /* v != "1" */
+  ZKE_D_DOMAIN_MISMATCH      = 5,  /* i= does not end with d= */
+  ZKE_D_FROM_NOT_SIGNED      = 6,  /* h= lacks "from" */
+  ZKE_D_BAD_QUERY_METHOD     = 7,  /* q= present and != "dns/txt" */
+  ZKE_D_BAD_CANON            = 8,  /* c= not one of the six accepted spellings */
+  ZKE_D_BAD_ALGO             = 9,  /* a= not rsa-sha1 / rsa-sha256 / ed25519-sha256 */
+  ZKE_D_BAD_LENGTH           = 10, /* l= not a decimal usize */
+  ZKE_D_BODY_HASH_MISMATCH   = 11, /* base64(SHA-256(canon body)) != bh= */
+  ZKE_D_SIG_B64              = 12, /* b= is not canonical padded base64 */
+  ZKE_D_SIG_MISMATCH         = 13, /* RSASSA-PKCS1-v1_5 verification failed */
+  /* ZKE_PARSE_FAIL */
+  ZKE_D_HDR_LEADING_SPACE    = 20, /* header line starts with ' ' */
+  ZKE_D_HDR_LONE_CR          = 21, /* headers followed by a lone CR */
+  ZKE_D_EMPTY_INPUT          = 22,
+  /* ZKE_KEY_DECODE_FAIL */
+  ZKE_D_KEY_TYPE             = 30, /* key_type not "rsa"/"ed25519" */
+  ZKE_D_KEY_DER              = 31, /* not a DER RSAPublicKey */
+  ZKE_D_KEY_RANGE            = 32, /* modulus > 4096 bits, e < 2 or e > 2^33-1 */
+  /* ZKE_CANON_FAIL */
+  ZKE_D_NO_SIGNATURE         = 40, /* no DKIM-Signature header at all */
+  /* ZKE_UNSUPPORTED */
+  ZKE_D_U_ALGO_SHA1          = 50, /* a=rsa-sha1 */
+  ZKE_D_U_ALGO_ED25519       = 51, /* a=ed25519-sha256 or key_type "ed25519" */
+  ZKE_D_U_SIG_NON_ASCII      = 52, /* DKIM-Signature value has bytes >= 0x80 (reference goes through from_utf8_lossy) */
+  ZKE_D_U_TOO_MANY_HEADERS   = 53, /* more than ZKE_MAX_HEADERS header fields */
+  ZKE_D_U_PREIMAGE_OVERFLOW  = 54, /* canonicalised header preimage exceeds its scratch slot */
+  ZKE_D_U_EVEN_MODULUS       = 55,
+  ZKE_D_U_TOO_MANY_TAGS      = 56,
+  ZKE_D_U_CAPTURE_FFFD       = 57, /* capture holds U+FFFD and the match text is not valid UTF-8 */
+  ZKE_D_U_EMAIL_TOO_LARGE    = 58, /* raw email >= 2^31 bytes */
+  /* regex */
+  ZKE_D_RE_MATCH_COUNT       = 60, /* find_iter(..).count() != 1      core/src/regex.rs:37 */
+  ZKE_D_RE_CAPTURE_MISSING   = 61, /* !matched_str.contains(capture)  core/src/regex.rs:44 */
+  ZKE_D_RE_QUIT              = 62  /* DFA entered its quit state (find_iter panics in the reference) */
+};
+
+#define ZKE_MAX_HEADERS 512u   /* header fields per email the device parser tables hold */
+#define ZKE_MAX_TAGS    32u    /* tag-specs per DKIM-Signature */
+#define ZKE_MAX_RSA_BYTES 512u /* RSA-4096, the rsa crate's ceiling (rsa 0.9.6 RsaPublicKey::MAX_SIZE) */
+#define ZKE_KEY_RSA 0u
+#define ZKE_KEY_ED25519 1u
+#define ZKE_KEY_OTHER 2u
+
+/* flags in zke_result.flags */
+#define ZKE_F_HDR_RELAXED  1u
+#define ZKE_F_BODY_RELAXED 2u
+#define ZKE_F_HAS_LENGTH   4u
+
+/* ------------------------------------------------------------------ result record */
+/* Fixed 192-byte record per email.  from_domain_hash / public_key_hash are the
+ * EmailVerifierOutput witnesses (core/src/circuits.rs:16-17); body_hash, header_hash,
+ * lengths and the match span are intermediates exposed so parity is checkable
+ * (SURVEY.md §0 item 5). external_inputs / regex_matches are echoes of the inputs
+ * (circuits.rs:18-27, regex.rs:47) and are reassembled by the host wrapper. */
+typedef struct zke_result {
+  uint32_t status;            /* ZKE_* */
+  uint32_t detail;            /* ZKE_D_* */
+  uint32_t sig_index;         /* index among DKIM-Signature headers (file order) that passed / was tried last */
+  uint32_t flags;             /* ZKE_F_* of that signature */
+  uint32_t canon_header_len;  /* bytes in the header-hash preimage */
+  uint32_t canon_body_len;    /* bytes hashed for bh (after l=) */
+  uint32_t body_offset;       /* offset of the body in raw_email (first CRLFCRLF + 4) */
+  uint32_t n_headers;         /* header fields mailparse would return */
+  uint8_t  from_domain_hash[32];
+  uint8_t  public_key_hash[32];
+  uint8_t  body_hash[32];     /* SHA-256(canon body[..l]) of the signature in sig_index */
+  uint8_t  header_hash[32];   /* SHA-256(header preimage) */
+  uint32_t regex_part;        /* part index (header parts first, then body parts) checked last; 0xFFFFFFFF if none */
+  uint32_t match_count;       /* matches found in that part, saturating at 2 */
+  uint32_t match_start;       /* span of its first match */
+  uint32_t match_end;
+  uint32_t rsa_bits;          /* modulus bit length */
+  uint32_t reserved[3];
+} zke_result;
+
+/* ------------------------------------------------------------------ batch input */
+/* Struct-of-arrays view of &[Email] / &[EmailWithRegex] (core/src/structs.rs:49-62).
+ * Caller-owned, read-only for the call.  In zke_verify_batch the pointers are host
+ * memory; in zke_verify_batch_device they are device (HBM) pointers. */
+typedef struct zke_batch {
+  uint32_t n;                      /* emails */
+  const uint8_t*  raw_blob;        /* Email.raw_email, concatenated            structs.rs:51 */
+  const uint64_t* raw_off;         /* [n+1] */
+  const uint8_t*  domain_blob;     /* Email.from_domain (UTF-8)                structs.rs:50 */
+  const uint64_t* domain_off;      /* [n+1] */
+  const uint8_t*  key_blob;        /* Email.public_key.key (PKCS#1 DER for rsa) structs.rs:9 */
+  const uint64_t* key_off;         /* [n+1] */
+  const uint8_t*  key_type;        /* [n] ZKE_KEY_*  (PublicKey.key_type)      structs.rs:10 */
+  const uint8_t*  ext_null;        /* [n] or NULL: 1 if any ExternalInput.value is None (circuits.rs:24) */
+
+  /* regex section (EmailWithRegex.regex_info, structs.rs:32-35,59-62).  The part list
+   * is shared by the batch (one regex_config per batch); captures are per email. */
+  uint32_t with_regex;             /* 0: verify_email; 1: verify_email_with_regex */
+  uint32_t n_header_parts;
+  uint32_t n_body_parts;
+  const uint32_t* header_part_ids; /* [n_header_parts] ids from zke_dfa_register */
+  const uint32_t* body_part_ids;   /* [n_body_parts] */
+  /* captures of email i, part p (p over header parts then body parts, P = total):
+   * strings cap_str_off[ cap_off[i*P+p] .. cap_off[i*P+p+1] ) in cap_blob. */
+  const uint32_t* cap_off;         /* [n*P + 1] or NULL when P == 0 */
+  const uint32_t* cap_str_off;     /* [n_strings + 1] */
+  const uint8_t*  cap_blob;
+} zke_batch;
+
+/* Optional copies of the intermediates, for parity tests (host mode only).  Any
+ * pointer may be NULL.  Slot i of a blob starts at i*stride. */
+typedef struct zke_debug_out {
+  uint8_t* canon_header; size_t canon_header_stride;  /* header-hash preimage */
+  uint8_t* canon_body;   size_t canon_body_stride;    /* canonicalised body (before l=) */
+  uint8_t* clean_body;   size_t clean_body_stride;    /* after remove_quoted_printable_soft_breaks (email.rs:61-86) */
+  uint8_t* em;           size_t em_stride;            /* sig^e mod n, big-endian, k bytes */
+  uint32_t* canon_body_full_len;                      /* [n] canonical body length before l= */
+} zke_debug_out;
+
+typedef struct zke_options {
+  int32_t  device;        /* HIP device ordinal; -1 = current */
+  uint32_t reserved[7];
+} zke_options;
+
+typedef struct zke_engine zke_engine;
+
+/* Per-kernel device time of the last batch, microseconds (HIP events on the engine's stream). */
+typedef struct zke_timings {
+  float parse_us, canon_body_us, sha_us, rsa_us, qp_us, dfa_us, finalize_us, total_us;
+  float h2d_us, d2h_us;
+} zke_timings;
+
+/* All functions return 0 on success, or a negative code if the CALL failed (bad
+ * arguments, device error, extension missing).  They never abort on a bad email. */
+#define ZKE_E_ARG     (-1)
+#define ZKE_E_DEVICE  (-2)
+#define ZKE_E_NOMEM   (-3)
+#define ZKE_E_DFA     (-4)
+
+int zke_engine_create(const zke_options* opt, zke_engine** out);
+void zke_engine_destroy(zke_engine* e);
+const char* zke_last_error(const zke_engine* e);
+
+/* Parse one regex-automata 0.4 dense-DFA pair once (replaces the per-email
+ * dense::DFA::from_bytes of core/src/regex.rs:32-33), validate it and stage a repacked
+ * transition table on the device.  Accepts unaligned input, so the align_slice shim
+ * (core/src/regex.rs:5-13) is unnecessary.  A blob that from_bytes would reject still
+ * gets an id; emails using it report ZKE_DFA_DECODE_FAIL. */
+int zke_dfa_register(zke_engine* e, const uint8_t* fwd, size_t fwd_len,
+                     const uint8_t* bwd, size_t bwd_len, uint32_t* out_id);
+
+/* Host-memory batch: copies inputs to HBM, runs the device pipeline, copies n records back. */
+int zke_verify_batch(zke_engine* e, const zke_batch* in, zke_result* out, zke_debug_out* dbg);
+
+/* Device-resident batch: every pointer in `in` and `out_dev` is device memory;
+ * `raw_total`, `domain_total`, `key_total` are the blob sizes (the CSR tails), which the
+ * host needs for workspace sizing without a device read.  Enqueues on `stream`
+ * (a hipStream_t, NULL = the engine's own stream) and returns without synchronising. */
+int zke_verify_batch_device(zke_engine* e, const zke_batch* in, uint64_t raw_total,
+                            uint64_t domain_total, uint64_t key_total,
+                            zke_result* out_dev, void* stream);
+int zke_engine_sync(zke_engine* e);
+int zke_get_timings(zke_engine* e, zke_timings* t);
+/* Enable per-kernel HIP-event timing (adds event records between kernels). */
+int zke_set_timing(zke_engine* e, int enabled);
+
+/* Single-email wrappers over a batch of one (config 1 / API-shape parity). */
+int zke_verify_email(zke_engine* e, const uint8_t* raw, size_t raw_len,
+                     const char* from_domain, size_t domain_len,
+                     const uint8_t* key, size_t key_len, uint32_t key_type,
+                     zke_result* out);
+
+/* Building blocks, exported for parity tests and micro-benchmarks.  Host pointers. */
+/* n messages msg_blob[off[i]..off[i+1]) -> digests[32*i..]           (core/src/crypto.rs:3-7) */
+int zke_sha256_batch(zke_engine* e, const uint8_t* msg_blob, const uint64_t* off,
+                     uint32_t n, uint8_t* digests);
+/* n RSA public-key operations: em[i] = sig[i]^e[i] mod n[i].  sig/mod big-endian,
+ * `bytes` each (<= 512, multiple of 4); em big-endian `bytes` each.  ok[i] = 0 when
+ * sig >= n or n even.  */
+int zke_rsa_modexp_batch(zke_engine* e, const uint8_t* sig, const uint8_t* mod,
+                         const uint64_t* exp, uint32_t bytes, uint32_t n,
+                         uint8_t* em, uint8_t* ok);
+/* Device-resident SHA-256 micro-benchmark entry: messages already in HBM. */
+int zke_sha256_batch_device(zke_engine* e, const uint8_t* msg_blob_dev, const uint64_t* off_dev,
+                            uint32_t n, uint8_t* digests_dev, void* stream);
+
+/* Library / build identification. */
+const char* zke_version(void);
+/* 1 if a HIP device is usable from this process, else 0 (never falls back to a CPU path). */
+int zke_device_available(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZKEMAIL_AMD_H */

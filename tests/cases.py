@@ -1,0 +1,182 @@
+"""Case corpus shared by the oracle tests (CPU) and the GPU parity tests.
+
+Every case is produced by the independent Python signer in zkemail_rs_amd.synth (RFC 6376
+stated in Python) or hand-written; expectations are derived here, never from the oracle.
+"""
+from __future__ import annotations
+
+import base64
+import hashlib
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+from zkemail_rs_amd import _abi as A
+from zkemail_rs_amd import synth
+from zkemail_rs_amd._abi import Email, PublicKey
+from zkemail_rs_amd.synth import SignSpec, sign_email
+
+
+@dataclass
+class Case:
+    name: str
+    email: Email
+    status: int = A.ZKE_OK
+    detail: Optional[int] = None
+    inter: Optional[dict] = None       # synth intermediates (canon_header, canon_body, hashes, em)
+    ext_null: bool = False
+    check_inter: bool = True
+
+
+def _hdrs(i=0, domain="example.com"):
+    rng = np.random.default_rng(100 + i)
+    return synth.std_headers(rng, i, domain)
+
+
+def _body(n=300, seed=0, qp=0.0):
+    return synth.ascii_body(np.random.default_rng(seed), n, qp_frac=qp)
+
+
+def K(name="rsa2048_00"):
+    return synth.load_keys()[name]
+
+
+def mk(name, headers, body, key, spec=None, status=A.ZKE_OK, detail=None, corrupt=None, from_domain=None,
+       pubkey=None, key_type="rsa", mutate=None, check_inter=True) -> Case:
+    spec = spec or SignSpec()
+    raw, inter = sign_email(headers, body, key, spec, corrupt=corrupt)
+    if mutate:
+        raw = mutate(raw)
+    em = Email(from_domain if from_domain is not None else spec.domain, raw,
+               PublicKey(pubkey if pubkey is not None else key.pkcs1_der, key_type))
+    return Case(name, em, status, detail, inter, check_inter=check_inter)
+
+
+def build_cases() -> List[Case]:
+    cs: List[Case] = []
+    k0 = K()
+    # ---- passing, the four canonicalisation pairs
+    for hc in ("relaxed", "simple"):
+        for bc in ("relaxed", "simple"):
+            cs.append(mk(f"pass_{hc}_{bc}", _hdrs(1), _body(300, 1), k0, SignSpec(header_canon=hc, body_canon=bc)))
+    # c= spellings cfdkim accepts (parser::parse_canonicalization)
+    cs.append(mk("pass_c_relaxed_only", _hdrs(2), _body(200, 2), k0, SignSpec(header_canon="relaxed", body_canon="simple", c_tag="relaxed")))
+    cs.append(mk("pass_c_simple_only", _hdrs(2), _body(200, 2), k0, SignSpec(header_canon="simple", body_canon="simple", c_tag="simple")))
+    cs.append(mk("pass_c_absent", _hdrs(2), _body(200, 2), k0, SignSpec(header_canon="simple", body_canon="simple", omit_c=True)))
+    # key sizes / exponents
+    for kn in ("rsa1024_00", "rsa2048_05", "rsa3072_00", "rsa4096_00", "rsa4096_09", "rsa2048e3_00"):
+        cs.append(mk(f"pass_key_{kn}", _hdrs(3), _body(500, 3), K(kn)))
+    # body shapes (relaxed): WSP runs, tabs, trailing WSP, trailing empty lines, no final CRLF
+    messy = b"Hello \t  world  \r\n\tindented\tline \t\r\n\r\nlast line  with   runs\r\n \r\n\t\r\n\r\n\r\n"
+    cs.append(mk("pass_relaxed_messy_body", _hdrs(4), messy, k0))
+    cs.append(mk("pass_simple_trailing_blank", _hdrs(4), b"line one\r\nline two\r\n\r\n\r\n\r\n", k0, SignSpec(body_canon="simple")))
+    cs.append(mk("pass_relaxed_no_final_crlf", _hdrs(4), b"no newline at end", k0))
+    cs.append(mk("pass_simple_no_final_crlf", _hdrs(4), b"no newline at end", k0, SignSpec(body_canon="simple")))
+    cs.append(mk("pass_empty_body_simple", _hdrs(4), b"", k0, SignSpec(body_canon="simple")))
+    cs.append(mk("pass_empty_body_relaxed", _hdrs(4), b"", k0))
+    cs.append(mk("pass_body_lone_cr_lf", _hdrs(4), b"a\rb\nc \r \nd\r\n", k0))
+    cs.append(mk("pass_body_64_boundary", _hdrs(5), _body(64 * 3 - 9, 5), k0))       # exactly fills the padding block
+    cs.append(mk("pass_body_119", _hdrs(5), _body(119, 6), k0))
+    cs.append(mk("pass_body_4096", _hdrs(5), _body(4096, 7), k0))
+    cs.append(mk("pass_body_70000", _hdrs(5), _body(70000, 8), k0))
+    # l= truncation
+    cs.append(mk("pass_length_tag", _hdrs(6), _body(400, 9), k0, SignSpec(length=100)))
+    cs.append(mk("pass_length_zero", _hdrs(6), _body(400, 9), k0, SignSpec(length=0)))
+    cs.append(mk("pass_length_beyond", _hdrs(6), _body(80, 9), k0, SignSpec(length=5000)))
+    # folded / duplicated headers, mixed case names, h= naming a header twice and a missing one
+    hs = [
+        (b"Received", b"from a.example.net\r\n\tby b.example.net;\r\n Tue, 03 Oct 2026 10:00:00 +0000"),
+        (b"Received", b"from c.example.net by d.example.net; Tue, 03 Oct 2026 09:59:00 +0000"),
+        (b"FROM", b"Alice   <alice@example.com>"),
+        (b"to", b"bob@example.net,\r\n   carol@example.net"),
+        (b"Subject", b"  spaced \t subject  "),
+        (b"Subject", b"second subject"),
+        (b"Date", b"Tue, 03 Oct 2026 10:00:00 +0000"),
+        (b"Message-ID", b"<dup@example.com>"),
+    ]
+    for hc in ("relaxed", "simple"):
+        if hc == "simple":   # simple keeps the wire bytes; avoid values that start with extra WSP (quirk case below)
+            hs = [(n, v.lstrip(b" ")) for n, v in hs]
+        cs.append(mk(f"pass_dup_folded_{hc}", hs, _body(150, 10), k0,
+                     SignSpec(header_canon=hc, signed=("From", "to", "subject", "Subject", "subject", "received", "date", "x-missing", "Received"))))
+    # i= within d=, extra tags, unfolded signature
+    cs.append(mk("pass_identity", _hdrs(7), _body(100, 11), k0, SignSpec(identity="@mail.example.com", domain="example.com")))
+    cs.append(mk("pass_extra_tags_unfolded", _hdrs(7), _body(100, 11), k0, SignSpec(extra_tags="t=1790000000; x=1790000100; q=dns/txt; ", fold_sig=False)))
+    cs.append(mk("pass_domain_case", _hdrs(7), _body(100, 11), k0, SignSpec(domain="Example.COM"), from_domain="eXAMPLE.com"))
+    cs.append(mk("pass_sig_header_lowercase_name", _hdrs(7), _body(100, 11), k0, SignSpec(sig_header_name=b"dkim-signature"), check_inter=False))
+
+    # ---- failing
+    cs.append(mk("fail_body_flipped", _hdrs(8), _body(300, 12), k0, corrupt="body", status=A.ZKE_DKIM_NOT_PASS, detail=A.D_BODY_HASH_MISMATCH, check_inter=False))
+    cs.append(mk("fail_header_flipped", _hdrs(8), _body(300, 12), k0, corrupt="header", status=A.ZKE_DKIM_NOT_PASS, detail=A.D_SIG_MISMATCH, check_inter=False))
+    cs.append(mk("fail_wrong_key", _hdrs(8), _body(300, 12), k0, pubkey=K("rsa2048_01").pkcs1_der, status=A.ZKE_DKIM_NOT_PASS, detail=A.D_SIG_MISMATCH, check_inter=False))
+    cs.append(mk("fail_wrong_key_size", _hdrs(8), _body(300, 12), k0, pubkey=K("rsa4096_00").pkcs1_der, status=A.ZKE_DKIM_NOT_PASS, detail=A.D_SIG_MISMATCH, check_inter=False))
+    cs.append(mk("fail_domain_other", _hdrs(8), _body(300, 12), k0, from_domain="other.org", status=A.ZKE_DKIM_NOT_PASS, detail=A.D_NEUTRAL, check_inter=False))
+    cs.append(mk("fail_from_not_signed", _hdrs(8), _body(300, 12), k0, SignSpec(signed=("to", "subject")), status=A.ZKE_DKIM_NOT_PASS, detail=A.D_FROM_NOT_SIGNED, check_inter=False))
+    cs.append(mk("fail_identity_outside", _hdrs(8), _body(300, 12), k0, SignSpec(identity="@evil.org"), status=A.ZKE_DKIM_NOT_PASS, detail=A.D_DOMAIN_MISMATCH, check_inter=False))
+    cs.append(mk("fail_bad_query", _hdrs(8), _body(300, 12), k0, SignSpec(extra_tags="q=http; "), status=A.ZKE_DKIM_NOT_PASS, detail=A.D_BAD_QUERY_METHOD, check_inter=False))
+    cs.append(mk("fail_bad_canon", _hdrs(8), _body(300, 12), k0, SignSpec(c_tag="nofws/simple"), status=A.ZKE_DKIM_NOT_PASS, detail=A.D_BAD_CANON, check_inter=False))
+    cs.append(mk("fail_bad_algo", _hdrs(8), _body(300, 12), k0, SignSpec(algo="rsa-md5"), status=A.ZKE_DKIM_NOT_PASS, detail=A.D_BAD_ALGO, check_inter=False))
+    cs.append(mk("unsupported_sha1", _hdrs(8), _body(300, 12), k0, SignSpec(algo="rsa-sha1"), status=A.ZKE_UNSUPPORTED, detail=A.D_U_ALGO_SHA1, check_inter=False))
+    cs.append(mk("unsupported_ed25519_alg", _hdrs(8), _body(300, 12), k0, SignSpec(algo="ed25519-sha256"), status=A.ZKE_UNSUPPORTED, detail=A.D_U_ALGO_ED25519, check_inter=False))
+    cs.append(mk("unsupported_ed25519_key", _hdrs(8), _body(300, 12), k0, pubkey=b"\x01" * 32, key_type="ed25519", status=A.ZKE_UNSUPPORTED, detail=A.D_U_ALGO_ED25519, check_inter=False))
+    cs.append(mk("fail_key_type_unknown", _hdrs(8), _body(300, 12), k0, key_type="dsa", status=A.ZKE_KEY_DECODE_FAIL, detail=A.D_KEY_TYPE, check_inter=False))
+    cs.append(mk("fail_key_der_garbage", _hdrs(8), _body(300, 12), k0, pubkey=b"\x30\x03\x02\x01", status=A.ZKE_KEY_DECODE_FAIL, detail=A.D_KEY_DER, check_inter=False))
+    cs.append(mk("fail_key_spki_not_pkcs1", _hdrs(8), _body(300, 12), k0,
+                 pubkey=bytes.fromhex("30820122300d06092a864886f70d01010105000382010f00") + k0.pkcs1_der,
+                 status=A.ZKE_KEY_DECODE_FAIL, detail=A.D_KEY_DER, check_inter=False))
+    cs.append(mk("fail_key_exponent_one", _hdrs(8), _body(300, 12), k0, pubkey=synth.pkcs1_pub_der(k0.n, 1), status=A.ZKE_KEY_DECODE_FAIL, detail=A.D_KEY_RANGE, check_inter=False))
+    cs.append(mk("fail_version_2", _hdrs(8), _body(300, 12), k0, mutate=lambda r: r.replace(b"v=1;", b"v=2;", 1), status=A.ZKE_DKIM_NOT_PASS, detail=A.D_INCOMPATIBLE_VERSION, check_inter=False))
+    cs.append(mk("fail_missing_selector", _hdrs(8), _body(300, 12), k0, mutate=lambda r: r.replace(b" s=sel1;", b"", 1), status=A.ZKE_DKIM_NOT_PASS, detail=A.D_MISSING_TAG, check_inter=False))
+    cs.append(mk("fail_tag_syntax", _hdrs(8), _body(300, 12), k0, mutate=lambda r: r.replace(b"DKIM-Signature: v=1;", b"DKIM-Signature: =1;", 1), status=A.ZKE_DKIM_NOT_PASS, detail=A.D_SIG_SYNTAX, check_inter=False))
+    cs.append(mk("fail_bad_length_tag", _hdrs(8), _body(300, 12), k0, SignSpec(extra_tags="l=12x; "), status=A.ZKE_DKIM_NOT_PASS, detail=A.D_BAD_LENGTH, check_inter=False))
+    cs.append(mk("fail_sig_b64_unpadded", _hdrs(8), _body(300, 12), k0, SignSpec(fold_sig=False), mutate=lambda r: r.replace(b"==\r\nReceived", b"=\r\nReceived", 1), status=A.ZKE_DKIM_NOT_PASS, detail=A.D_SIG_B64, check_inter=False))
+    cs.append(mk("fail_no_signature", _hdrs(8), _body(300, 12), k0, mutate=lambda r: r[r.find(b"Received:"):], status=A.ZKE_DKIM_NOT_PASS, detail=A.D_NEUTRAL, check_inter=False))
+    cs.append(mk("fail_sig_truncated", _hdrs(8), _body(300, 12), k0, SignSpec(fold_sig=False),
+                 mutate=lambda r: _shorten_sig(r), status=A.ZKE_DKIM_NOT_PASS, detail=A.D_SIG_MISMATCH, check_inter=False))
+    cs.append(mk("unsupported_sig_non_ascii", _hdrs(8), _body(300, 12), k0, SignSpec(),
+                 mutate=lambda r: r.replace(b"s=sel1;", b"s=sel1; z=\xc3\xa9;", 1), status=A.ZKE_UNSUPPORTED, detail=A.D_U_SIG_NON_ASCII, check_inter=False))
+    # mailparse errors (core/src/email.rs:26)
+    cs.append(mk("parse_leading_space", _hdrs(8), _body(50, 1), k0, mutate=lambda r: b" bad start\r\n" + r, status=A.ZKE_PARSE_FAIL, detail=A.D_HDR_LEADING_SPACE, check_inter=False))
+    cs.append(mk("parse_lone_cr", _hdrs(8), _body(50, 1), k0, mutate=lambda r: r.replace(b"\r\n\r\n", b"\r\n\rX\r\n\r\n", 1), status=A.ZKE_PARSE_FAIL, detail=A.D_HDR_LONE_CR, check_inter=False))
+    # multiple signatures: a foreign-domain one first, then ours
+    cs.append(_two_sigs())
+    cs.append(_two_sigs(first_broken=True))
+    # cfdkim (recalled) rebuilds simple headers as "key: value" from mailparse's pair, so a signer that
+    # hashed the wire bytes "Subject:   x" (RFC simple) does not verify under the reference
+    cs.append(mk("quirk_simple_header_leading_space", [(b"From", b"a@example.com"), (b"Subject", b"  two leading spaces")],
+                 _body(90, 3), k0, SignSpec(header_canon="simple", signed=("from", "subject")),
+                 status=A.ZKE_DKIM_NOT_PASS, detail=A.D_SIG_MISMATCH, check_inter=False))
+    cs.append(Case("empty_input", Email("example.com", b"", PublicKey(k0.pkcs1_der)), A.ZKE_DKIM_NOT_PASS, A.D_NEUTRAL, None, check_inter=False))
+    cs.append(Case("headers_only_no_blank", Email("example.com", b"From: a@example.com\r\nSubject: x", PublicKey(k0.pkcs1_der)), A.ZKE_DKIM_NOT_PASS, A.D_NEUTRAL, None, check_inter=False))
+    c = mk("ext_null", _hdrs(9), _body(100, 2), k0, status=A.ZKE_EXTERNAL_INPUT_NULL, check_inter=False)
+    c.email.external_inputs = [A.ExternalInput("name", None, 8)]
+    cs.append(c)
+    return cs
+
+
+def _shorten_sig(raw: bytes) -> bytes:
+    """Drop the first 4 base64 chars of b= (3 bytes): still valid base64, wrong length."""
+    i = raw.find(b" b=") + 3
+    return raw[:i] + raw[i + 4:]
+
+
+def _two_sigs(first_broken: bool = False) -> Case:
+    """File order: [first signature][ours][headers].  Ours signs only from/to/subject/date/message-id,
+    so the other DKIM-Signature header does not enter its preimage."""
+    k0, k1 = K("rsa2048_00"), K("rsa2048_01")
+    hs = _hdrs(20)
+    body = _body(222, 20)
+    raw, inter = sign_email(hs, body, k0, SignSpec())
+    if first_broken:   # same domain, body hash of a different body: tried first, fails, then ours passes
+        raw_other, _ = sign_email(hs, _body(100, 21), k0, SignSpec(selector="old"))
+        name = "pass_second_signature_after_failed_first"
+    else:              # foreign domain: skipped without error
+        raw_other, _ = sign_email(hs, body, k1, SignSpec(domain="other.org", selector="o1"))
+        name = "pass_two_signatures"
+    other_sig_hdr = raw_other[:raw_other.find(b"Received:")]
+    return Case(name, Email("example.com", other_sig_hdr + raw, PublicKey(k0.pkcs1_der)), A.ZKE_OK, None, inter)
+
+
+def expected_witness(c: Case):
+    return (hashlib.sha256(c.email.from_domain.encode()).digest(), hashlib.sha256(c.email.public_key.key).digest())

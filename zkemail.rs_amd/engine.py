@@ -1,0 +1,247 @@
+"""ctypes binding of libzkemail_amd.so and the Python mirror of ``verify_email`` /
+``verify_email_with_regex`` (core/src/circuits.rs:9-68).
+
+The mirror keeps the reference's names, argument meaning and error behaviour: where the
+reference panics (``assert!`` / ``unwrap`` / ``expect``) these raise :class:`VerifyPanic`
+carrying the status that names the panic site.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _abi as A
+from ._abi import (CompiledRegex, DebugBuffers, Email, EmailVerifierOutput, EmailWithRegex,
+                   EmailWithRegexVerifierOutput, PackedBatch)
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_PKG, "libzkemail_amd.so")
+_lib = None
+
+
+class EngineError(RuntimeError):
+    """The C-ABI call itself failed (bad arguments, no device, library missing)."""
+
+
+class VerifyPanic(AssertionError):
+    """The reference would have panicked on this e-mail (status names the site)."""
+
+    def __init__(self, status: int, detail: int, index: int = 0):
+        self.status, self.detail, self.index = status, detail, index
+        super().__init__(f"email {index}: {A.STATUS_NAMES.get(status, status)} (detail {detail}) — "
+                         f"reference panics at {A.STATUS_SITE.get(status, '?')}")
+
+
+def load_library(path: Optional[str] = None):
+    """Load the HIP engine.  Fails loudly: there is no CPU implementation behind this API."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or _LIB_PATH
+    if not os.path.exists(p):
+        raise EngineError(f"{p} not built — run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(p)
+    vp, u32p = C.c_void_p, C.POINTER(C.c_uint32)
+    lib.zke_engine_create.argtypes = [C.POINTER(A.zke_options), C.POINTER(vp)]
+    lib.zke_engine_create.restype = C.c_int
+    lib.zke_engine_destroy.argtypes = [vp]
+    lib.zke_engine_destroy.restype = None
+    lib.zke_last_error.argtypes = [vp]
+    lib.zke_last_error.restype = C.c_char_p
+    lib.zke_dfa_register.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, u32p]
+    lib.zke_dfa_register.restype = C.c_int
+    lib.zke_verify_batch.argtypes = [vp, C.POINTER(A.zke_batch), vp, C.POINTER(A.zke_debug_out)]
+    lib.zke_verify_batch.restype = C.c_int
+    lib.zke_verify_batch_device.argtypes = [vp, C.POINTER(A.zke_batch), C.c_uint64, C.c_uint64, C.c_uint64, vp, vp]
+    lib.zke_verify_batch_device.restype = C.c_int
+    lib.zke_engine_sync.argtypes = [vp]
+    lib.zke_engine_sync.restype = C.c_int
+    lib.zke_get_timings.argtypes = [vp, C.POINTER(A.zke_timings)]
+    lib.zke_get_timings.restype = C.c_int
+    lib.zke_set_timing.argtypes = [vp, C.c_int]
+    lib.zke_set_timing.restype = C.c_int
+    lib.zke_verify_email.argtypes = [vp, vp, C.c_size_t, C.c_char_p, C.c_size_t, vp, C.c_size_t, C.c_uint32, vp]
+    lib.zke_verify_email.restype = C.c_int
+    lib.zke_sha256_batch.argtypes = [vp, vp, vp, C.c_uint32, vp]
+    lib.zke_sha256_batch.restype = C.c_int
+    lib.zke_sha256_batch_device.argtypes = [vp, vp, vp, C.c_uint32, vp, vp]
+    lib.zke_sha256_batch_device.restype = C.c_int
+    lib.zke_rsa_modexp_batch.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_uint32, vp, vp]
+    lib.zke_rsa_modexp_batch.restype = C.c_int
+    lib.zke_version.argtypes = []
+    lib.zke_version.restype = C.c_char_p
+    lib.zke_device_available.argtypes = []
+    lib.zke_device_available.restype = C.c_int
+    if path is None:
+        _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = [
+    "zke_engine_create", "zke_engine_destroy", "zke_last_error", "zke_dfa_register", "zke_verify_batch",
+    "zke_verify_batch_device", "zke_engine_sync", "zke_get_timings", "zke_set_timing", "zke_verify_email",
+    "zke_sha256_batch", "zke_sha256_batch_device", "zke_rsa_modexp_batch", "zke_version", "zke_device_available",
+]
+
+
+class Engine:
+    """One engine per GPU (``zke_engine``): owns the device workspace, the stream and the
+    registered DFA tables."""
+
+    def __init__(self, device: int = -1):
+        self.lib = load_library()
+        if not self.lib.zke_device_available():
+            raise EngineError("no HIP device visible; the engine has no CPU path")
+        opt = A.zke_options()
+        opt.device = device
+        h = C.c_void_p()
+        rc = self.lib.zke_engine_create(C.byref(opt), C.byref(h))
+        if rc != 0:
+            raise EngineError(f"zke_engine_create failed ({rc})")
+        self.h = h
+        self._dfa_cache: Dict[Tuple[bytes, bytes], int] = {}
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.zke_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            msg = self.lib.zke_last_error(self.h)
+            raise EngineError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    # ---- registration (replaces the per-email DFA::from_bytes of core/src/regex.rs:32-33)
+    def dfa_register(self, fwd: bytes, bwd: bytes) -> int:
+        key = (bytes(fwd), bytes(bwd))
+        if key in self._dfa_cache:
+            return self._dfa_cache[key]
+        out = C.c_uint32()
+        f = (C.c_uint8 * max(len(fwd), 1)).from_buffer_copy(fwd or b"\0")
+        b = (C.c_uint8 * max(len(bwd), 1)).from_buffer_copy(bwd or b"\0")
+        self._check(self.lib.zke_dfa_register(self.h, C.addressof(f), len(fwd), C.addressof(b), len(bwd),
+                                              C.byref(out)), "zke_dfa_register")
+        self._dfa_cache[key] = out.value
+        return out.value
+
+    # ---- batches
+    def verify_batch(self, batch: PackedBatch, debug: Optional[DebugBuffers] = None) -> np.ndarray:
+        out = np.zeros(max(batch.n, 1), dtype=A.RESULT_DTYPE)
+        self._check(self.lib.zke_verify_batch(self.h, C.byref(batch.c), out.ctypes.data,
+                                              C.byref(debug.c) if debug is not None else None), "zke_verify_batch")
+        return out[:batch.n]
+
+    def verify_batch_device(self, cbatch: A.zke_batch, raw_total: int, domain_total: int, key_total: int,
+                            out_dev_ptr: int, stream: int = 0):
+        self._check(self.lib.zke_verify_batch_device(self.h, C.byref(cbatch), raw_total, domain_total, key_total,
+                                                     out_dev_ptr, stream), "zke_verify_batch_device")
+
+    def sync(self):
+        self._check(self.lib.zke_engine_sync(self.h), "zke_engine_sync")
+
+    def set_timing(self, on: bool):
+        self._check(self.lib.zke_set_timing(self.h, 1 if on else 0), "zke_set_timing")
+
+    def timings(self) -> dict:
+        t = A.zke_timings()
+        self._check(self.lib.zke_get_timings(self.h, C.byref(t)), "zke_get_timings")
+        return {k: getattr(t, k) for k, _ in A.zke_timings._fields_}
+
+    # ---- building blocks
+    def sha256_batch(self, msgs: Sequence[bytes]) -> np.ndarray:
+        """hash_bytes (core/src/crypto.rs:3-7) over a list of messages, on the GPU."""
+        blob, off = A._csr(list(msgs))
+        out = np.zeros((max(len(msgs), 1), 32), np.uint8)
+        self._check(self.lib.zke_sha256_batch(self.h, blob.ctypes.data, off.ctypes.data, len(msgs), out.ctypes.data),
+                    "zke_sha256_batch")
+        return out[:len(msgs)]
+
+    def rsa_modexp_batch(self, sigs: Sequence[bytes], mods: Sequence[bytes], exps: Sequence[int], nbytes: int):
+        n = len(sigs)
+        s = np.frombuffer(b"".join(x.rjust(nbytes, b"\0") for x in sigs), np.uint8).copy()
+        m = np.frombuffer(b"".join(x.rjust(nbytes, b"\0") for x in mods), np.uint8).copy()
+        e = np.array(list(exps), dtype=np.uint64)
+        em = np.zeros((n, nbytes), np.uint8)
+        ok = np.zeros(n, np.uint8)
+        self._check(self.lib.zke_rsa_modexp_batch(self.h, s.ctypes.data, m.ctypes.data, e.ctypes.data, nbytes, n,
+                                                  em.ctypes.data, ok.ctypes.data), "zke_rsa_modexp_batch")
+        return em, ok
+
+    # ---- zkemail_core mirror
+    def verify_emails(self, emails: Sequence[Email]) -> np.ndarray:
+        return self.verify_batch(PackedBatch(emails))
+
+    def pack_with_regex(self, inputs: Sequence[EmailWithRegex]) -> PackedBatch:
+        """All inputs must share one part list (one regex_config per batch); captures are per e-mail."""
+        first = inputs[0].regex_info
+        hp = first.header_parts or []
+        bp = first.body_parts or []
+        hids = [self.dfa_register(p.verify_re.fwd, p.verify_re.bwd) for p in hp]
+        bids = [self.dfa_register(p.verify_re.fwd, p.verify_re.bwd) for p in bp]
+        caps = []
+        for inp in inputs:
+            h2, b2 = inp.regex_info.header_parts or [], inp.regex_info.body_parts or []
+            if [self.dfa_register(p.verify_re.fwd, p.verify_re.bwd) for p in h2] != hids or \
+               [self.dfa_register(p.verify_re.fwd, p.verify_re.bwd) for p in b2] != bids:
+                raise EngineError("a batch must share one part list; split it per regex_config")
+            caps.append([list(p.captures or []) for p in list(h2) + list(b2)])
+        return PackedBatch([i.email for i in inputs], hids, bids, caps, with_regex=True)
+
+    def verify_email(self, email: Email) -> EmailVerifierOutput:
+        """core/src/circuits.rs:9-29."""
+        r = self.verify_batch(PackedBatch([email]))[0]
+        if r["status"] != A.ZKE_OK:
+            raise VerifyPanic(int(r["status"]), int(r["detail"]))
+        return _email_output(email, r)
+
+    def verify_email_with_regex(self, inp: EmailWithRegex) -> EmailWithRegexVerifierOutput:
+        """core/src/circuits.rs:31-68."""
+        r = self.verify_batch(self.pack_with_regex([inp]))[0]
+        if r["status"] != A.ZKE_OK:
+            raise VerifyPanic(int(r["status"]), int(r["detail"]))
+        return EmailWithRegexVerifierOutput(_email_output(inp.email, r), regex_matches_of(inp))
+
+
+def _email_output(email: Email, r) -> EmailVerifierOutput:
+    ext: List[str] = []
+    for x in email.external_inputs:            # circuits.rs:18-27
+        ext += [x.name, x.value]
+    return EmailVerifierOutput(bytes(r["from_domain_hash"]), bytes(r["public_key_hash"]), ext)
+
+
+def regex_matches_of(inp: EmailWithRegex) -> List[str]:
+    """regex_matches = header captures ++ body captures (circuits.rs:58-62); the strings are the
+    *input* capture strings (regex.rs:47), valid only once the engine reported OK."""
+    out: List[str] = []
+    for parts in (inp.regex_info.header_parts, inp.regex_info.body_parts):
+        for p in parts or []:
+            out += list(p.captures or [])
+    return out
+
+
+_default: Optional[Engine] = None
+
+
+def default_engine() -> Engine:
+    global _default
+    if _default is None:
+        _default = Engine()
+    return _default
+
+
+def verify_email(email: Email) -> EmailVerifierOutput:
+    return default_engine().verify_email(email)
+
+
+def verify_email_with_regex(inp: EmailWithRegex) -> EmailWithRegexVerifierOutput:
+    return default_engine().verify_email_with_regex(inp)

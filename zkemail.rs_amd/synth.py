@@ -1,0 +1,342 @@
+"""Synthetic DKIM-signed e-mail generator (test / bench DATA only — never on the verify path).
+
+An independent Python statement of RFC 6376 signing: canonicalisation (§3.4), the
+DKIM-Signature tag list (§3.5), hash computation (§3.7) with ``hashlib`` and RSASSA-PKCS1-v1_5
+(RFC 8017 §8.2.1 / §9.2) with Python integers.  It deliberately shares no code with
+``oracle/`` or the HIP engine, so an e-mail it signs verifying under both is evidence, not a
+tautology.  The workloads follow SURVEY.md §8(d) / BASELINE.json ``configs``.
+"""
+from __future__ import annotations
+
+import base64
+import hashlib
+import json
+import os
+import re
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from ._abi import Email, PublicKey
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+KEYS_JSON = os.path.join(os.path.dirname(_HERE), "tests", "golden", "keys.json")
+
+SHA256_DIGESTINFO = bytes.fromhex("3031300d060960864801650304020105000420")
+
+
+# ------------------------------------------------------------------ keys
+@dataclass
+class RsaKey:
+    name: str
+    bits: int
+    n: int
+    e: int
+    d: int
+    p: int
+    q: int
+    pkcs1_der: bytes  # RSAPublicKey DER (what helpers/src/dkim.rs:50 hands to core)
+
+    @property
+    def k(self) -> int:
+        return (self.n.bit_length() + 7) // 8
+
+    def sign_em(self, em: bytes) -> bytes:
+        m = int.from_bytes(em, "big")
+        dp, dq = self.d % (self.p - 1), self.d % (self.q - 1)
+        qinv = pow(self.q, -1, self.p)
+        m1, m2 = pow(m % self.p, dp, self.p), pow(m % self.q, dq, self.q)
+        h = (qinv * (m1 - m2)) % self.p
+        s = m2 + h * self.q
+        return s.to_bytes(self.k, "big")
+
+
+def der_len(n: int) -> bytes:
+    if n < 0x80:
+        return bytes([n])
+    b = n.to_bytes((n.bit_length() + 7) // 8, "big")
+    return bytes([0x80 | len(b)]) + b
+
+
+def der_uint(v: int) -> bytes:
+    b = v.to_bytes(max(1, (v.bit_length() + 7) // 8), "big")
+    if b[0] & 0x80:
+        b = b"\x00" + b
+    return b"\x02" + der_len(len(b)) + b
+
+
+def pkcs1_pub_der(n: int, e: int) -> bytes:
+    body = der_uint(n) + der_uint(e)
+    return b"\x30" + der_len(len(body)) + body
+
+
+_KEY_CACHE: Optional[Dict[str, RsaKey]] = None
+
+
+def load_keys(path: str = KEYS_JSON) -> Dict[str, RsaKey]:
+    global _KEY_CACHE
+    if _KEY_CACHE is None or path != KEYS_JSON:
+        with open(path) as f:
+            raw = json.load(f)
+        keys = {}
+        for name, k in raw.items():
+            n, e, d, p, q = (int(k[x], 16) for x in ("n", "e", "d", "p", "q"))
+            keys[name] = RsaKey(name, k["bits"], n, e, d, p, q, bytes.fromhex(k["pkcs1_der"]))
+        if path != KEYS_JSON:
+            return keys
+        _KEY_CACHE = keys
+    return _KEY_CACHE
+
+
+def keys_of(bits: int, count: int) -> List[RsaKey]:
+    ks = [k for k in load_keys().values() if k.bits == bits and k.e == 65537]
+    ks.sort(key=lambda k: k.name)
+    assert len(ks) >= count, f"need {count} RSA-{bits} keys, have {len(ks)}"
+    return ks[:count]
+
+
+# ------------------------------------------------------------------ RFC 6376 §3.4
+def relaxed_header(name: bytes, value: bytes) -> bytes:
+    """§3.4.2: lower-case name, unfold, WSP runs -> SP, strip around the value."""
+    v = value.replace(b"\r\n", b"")
+    v = re.sub(rb"[ \t]+", b" ", v).strip(b" ")
+    return name.lower().rstrip(b" \t") + b":" + v + b"\r\n"
+
+
+def simple_header(name: bytes, value: bytes, sep: bytes = b": ") -> bytes:
+    """§3.4.1: the field exactly as transmitted."""
+    return name + sep + value + b"\r\n"
+
+
+def relaxed_body(body: bytes) -> bytes:
+    """§3.4.4 on CRLF-delimited lines."""
+    if body == b"":
+        return b""
+    lines = body.split(b"\r\n")
+    out = [re.sub(rb"[ \t]+", b" ", ln).rstrip(b" ") for ln in lines]
+    text = b"\r\n".join(out)
+    ends_crlf = body.endswith(b"\r\n")
+    if not ends_crlf:
+        text += b"\r\n"
+    while text.endswith(b"\r\n\r\n"):
+        text = text[:-2]
+    if text == b"\r\n":
+        # RFC: an all-empty-line body canonicalises to nothing.  (cfdkim's restatement keeps a
+        # lone CRLF; callers that need that quirk do not use this generator for it.)
+        return b""
+    return text
+
+
+def simple_body(body: bytes) -> bytes:
+    """§3.4.3."""
+    if body == b"":
+        return b"\r\n"
+    while body.endswith(b"\r\n\r\n"):
+        body = body[:-2]
+    return body
+
+
+def emsa_pkcs1_v15_sha256(digest: bytes, k: int) -> bytes:
+    t = SHA256_DIGESTINFO + digest
+    return b"\x00\x01" + b"\xff" * (k - len(t) - 3) + b"\x00" + t
+
+
+def fold_b64(s: str, first_room: int, width: int = 72, indent: bytes = b"\r\n ") -> bytes:
+    out, room, i = [], max(first_room, 8), 0
+    while i < len(s):
+        out.append(s[i:i + room].encode())
+        i += room
+        room = width
+    return indent.join(out)
+
+
+@dataclass
+class SignSpec:
+    domain: str = "example.com"
+    selector: str = "sel1"
+    header_canon: str = "relaxed"
+    body_canon: str = "relaxed"
+    signed: Sequence[str] = ("from", "to", "subject", "date", "message-id")
+    length: Optional[int] = None           # l=
+    identity: Optional[str] = None         # i=
+    algo: str = "rsa-sha256"
+    fold_sig: bool = True
+    extra_tags: str = ""                   # e.g. "t=1700000000; "
+    sig_header_name: bytes = b"DKIM-Signature"
+    c_tag: Optional[str] = None            # override the c= spelling ("relaxed", None = a/b)
+    omit_c: bool = False
+
+
+def select_headers(headers: List[Tuple[bytes, bytes]], names: Sequence[str]) -> List[Tuple[bytes, bytes]]:
+    """§5.4.2: repeated names take successively earlier instances, bottom-up."""
+    used: Dict[str, int] = {}
+    picked = []
+    for nm in names:
+        nml = nm.lower()
+        start = used.get(nml, len(headers))
+        for ix in range(start - 1, -1, -1):
+            if headers[ix][0].lower() == nml.encode():
+                picked.append(headers[ix])
+                used[nml] = ix
+                break
+        else:
+            used[nml] = 0
+    return picked
+
+
+def sign_email(headers: List[Tuple[bytes, bytes]], body: bytes, key: RsaKey, spec: SignSpec,
+               *, corrupt: Optional[str] = None) -> Tuple[bytes, dict]:
+    """Return (raw_email, intermediates).  ``headers`` are (name, value) with the value as it
+    follows ``": "`` on the wire (may contain folded ``\\r\\n `` continuations)."""
+    cbody_full = relaxed_body(body) if spec.body_canon == "relaxed" else simple_body(body)
+    cbody = cbody_full if spec.length is None else cbody_full[:spec.length]
+    bh = base64.b64encode(hashlib.sha256(cbody).digest()).decode()
+    ctag = spec.c_tag if spec.c_tag is not None else f"{spec.header_canon}/{spec.body_canon}"
+    tags = f"v=1; a={spec.algo}; "
+    if not spec.omit_c:
+        tags += f"c={ctag}; "
+    tags += f"d={spec.domain}; s={spec.selector}; {spec.extra_tags}"
+    if spec.identity:
+        tags += f"i={spec.identity}; "
+    if spec.length is not None:
+        tags += f"l={spec.length}; "
+    tags += "h=" + ":".join(spec.signed) + ";\r\n bh=" + bh + ";\r\n b="
+    sig_value_unsigned = tags.encode()
+    hc = relaxed_header if spec.header_canon == "relaxed" else simple_header
+    pre = b"".join(hc(n, v) for n, v in select_headers(headers, spec.signed))
+    pre += hc(spec.sig_header_name, sig_value_unsigned)[:-2]
+    hh = hashlib.sha256(pre).digest()
+    em = emsa_pkcs1_v15_sha256(hh, key.k)
+    sig = key.sign_em(em)
+    b64 = base64.b64encode(sig).decode()
+    sig_field = fold_b64(b64, 72 - 3) if spec.fold_sig else b64.encode()
+    sig_value = sig_value_unsigned + sig_field
+    all_headers = [(spec.sig_header_name, sig_value)] + list(headers)
+    raw = b"".join(n + b": " + v + b"\r\n" for n, v in all_headers) + b"\r\n" + body
+    if corrupt == "body" and len(body):
+        pos = len(raw) - len(body) + len(body) // 2
+        raw = raw[:pos] + bytes([raw[pos] ^ 0x01]) + raw[pos + 1:]
+    elif corrupt == "header":
+        ix = raw.find(b"Subject: ") + len(b"Subject: ")
+        raw = raw[:ix] + bytes([raw[ix] ^ 0x01]) + raw[ix + 1:]
+    inter = {
+        "canon_header": pre, "canon_body": cbody_full, "hashed_body_len": len(cbody),
+        "body_hash": hashlib.sha256(cbody).digest(), "header_hash": hh, "em": em, "sig": sig,
+    }
+    return raw, inter
+
+
+# ------------------------------------------------------------------ workloads
+_WORDS = ("lorem ipsum dolor sit amet consectetur adipiscing elit sed do eiusmod tempor incididunt ut labore et "
+          "dolore magna aliqua enim ad minim veniam quis nostrud exercitation ullamco laboris nisi aliquip ex ea "
+          "commodo consequat duis aute irure in reprehenderit voluptate velit esse cillum fugiat nulla pariatur").split()
+
+
+def ascii_body(rng: np.random.Generator, canon_len: int, qp_frac: float = 0.0) -> bytes:
+    """Printable-ASCII body in 76-column CRLF lines whose canonical form (relaxed or simple) is
+    exactly ``canon_len`` bytes: no WSP runs, no trailing WSP, no empty lines, final CRLF."""
+    n = canon_len
+    assert n >= 3
+    q, r = divmod(n, 78)
+    lens = [76] * q
+    if r >= 3:
+        lens.append(r - 2)
+    elif r > 0:                      # 1 or 2 bytes left over: shorten the previous line
+        if q == 0:
+            raise ValueError("canon_len too small")
+        lens[-1] -= (3 - r)
+        lens.append(1)
+    lens_a = np.array(lens, dtype=np.int64)
+    ends = np.cumsum(lens_a + 2)
+    assert int(ends[-1]) == n
+    alphabet = np.frombuffer(b"abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789.,;-", np.uint8)
+    buf = alphabet[rng.integers(0, len(alphabet), size=n)].copy()
+    sp = rng.random(n) < 0.15
+    sp[1:] &= ~sp[:-1]               # never two in a row
+    starts = ends - (lens_a + 2)
+    sp[starts] = False               # not at a line start
+    sp[ends - 3] = False             # nor right before the CRLF
+    buf[sp] = 0x20
+    buf[ends - 2] = 0x0D
+    buf[ends - 1] = 0x0A
+    out = buf.tobytes()
+    if qp_frac > 0:
+        lines = out.split(b"\r\n")
+        for i in range(len(lines) - 1):
+            if len(lines[i]) > 20 and rng.random() < qp_frac:
+                lines[i] = lines[i][:-1] + b"="   # soft break: the line now ends "=\r\n"
+        out = b"\r\n".join(lines)
+    return out
+
+
+def std_headers(rng: np.random.Generator, i: int, domain: str, pad_to: int = 0) -> List[Tuple[bytes, bytes]]:
+    user = "".join(_WORDS[int(x)] for x in rng.integers(0, len(_WORDS), 2))
+    subj = " ".join(_WORDS[int(x)] for x in rng.integers(0, len(_WORDS), 6))
+    hs = [
+        (b"Received", f"from mail-{i}.{domain} (mail-{i}.{domain} [192.0.2.{i % 250 + 1}])\r\n\tby mx.example.net with ESMTPS id {i:08x};\r\n\tTue, 03 Oct 2026 10:{i % 60:02d}:00 +0000".encode()),
+        (b"From", f"{user.title()} <{user}@{domain}>".encode()),
+        (b"To", f"Recipient {i} <rcpt{i}@example.net>".encode()),
+        (b"Subject", f"{subj} #{i}".encode()),
+        (b"Date", f"Tue, 03 Oct 2026 10:{i % 60:02d}:{(i // 60) % 60:02d} +0000".encode()),
+        (b"Message-ID", f"<{i:08x}.{int(rng.integers(0, 2**31)):08x}@{domain}>".encode()),
+        (b"MIME-Version", b"1.0"),
+        (b"Content-Type", b"text/plain; charset=us-ascii"),
+        (b"Content-Transfer-Encoding", b"quoted-printable"),
+    ]
+    if pad_to:
+        cur = sum(len(n) + 2 + len(v) + 2 for n, v in hs)
+        if pad_to > cur + 20:
+            fill = "x" * (pad_to - cur - len("X-Pad: \r\n"))
+            hs.append((b"X-Pad", fill.encode()))
+    return hs
+
+
+@dataclass
+class Workload:
+    name: str
+    emails: List[Email]
+    inter: List[dict]
+    body_bytes: int          # canonical body bytes hashed, summed (the SHA roofline numerator)
+    raw_bytes: int
+
+
+def make_workload(name: str, n: int, body_len: int, rsa_bits: int = 2048, n_keys: int = 16, seed: int = 2,
+                  ragged: bool = False, invalid_frac: float = 0.0, qp_frac: float = 0.0,
+                  header_canon: str = "relaxed", body_canon: str = "relaxed", domain_fmt: str = "example.com",
+                  hdr_pad: int = 760) -> Workload:
+    """Seeded batch of SURVEY §8(d)'s shape: CRLF, c=relaxed/relaxed, a=rsa-sha256,
+    h=from:to:subject:date:message-id, one DKIM-Signature, ≈1 KB of headers."""
+    rng = np.random.default_rng(seed)
+    keys = keys_of(rsa_bits, n_keys)
+    emails, inter, bsum, rsum = [], [], 0, 0
+    for i in range(n):
+        key = keys[i % len(keys)]
+        if ragged:
+            L = int(np.exp(rng.uniform(np.log(3), np.log(max(body_len, 4)))))
+            L = max(3, min(L, body_len))
+        else:
+            L = body_len
+        body = ascii_body(rng, L, qp_frac=qp_frac)
+        hs = std_headers(rng, i, domain_fmt, pad_to=hdr_pad)
+        spec = SignSpec(domain=domain_fmt, header_canon=header_canon, body_canon=body_canon)
+        corrupt = None
+        if invalid_frac and rng.random() < invalid_frac:
+            corrupt = "body" if rng.random() < 0.5 else "header"
+        raw, it = sign_email(hs, body, key, spec, corrupt=corrupt)
+        it["corrupt"] = corrupt
+        emails.append(Email(domain_fmt, raw, PublicKey(key.pkcs1_der, "rsa")))
+        inter.append(it)
+        bsum += it["hashed_body_len"]
+        rsum += len(raw)
+    return Workload(name, emails, inter, bsum, rsum)
+
+
+CONFIGS = {
+    # BASELINE.json configs[0..4]
+    "c1": dict(n=1, body_len=300, rsa_bits=2048, n_keys=1, seed=1, hdr_pad=0),
+    "c2": dict(n=1024, body_len=4096, rsa_bits=2048, n_keys=16, seed=2),
+    "c3": dict(n=4096, body_len=4096, rsa_bits=2048, n_keys=16, seed=3),
+    "c4": dict(n=65536, body_len=65536, rsa_bits=2048, n_keys=16, seed=4),
+    "c5": dict(n=16384, body_len=4096, rsa_bits=4096, n_keys=16, seed=5, qp_frac=0.05),
+}
