@@ -91,6 +91,8 @@ def test_canon_functions_vs_python(oracle):
         # the Python statement is line-based and assumes CRLF line ends; restrict to such bodies
         if b"\r" in body.replace(b"\r\n", b"") or b"\n" in body.replace(b"\r\n", b""):
             continue
+        if body.endswith((b" ", b"\t")):
+            continue   # unterminated last line ending in WSP: quirk asserted below
         got = oracle.canon_body(body, True)
         exp = synth.relaxed_body(body)
         if exp == b"" and body != b"":

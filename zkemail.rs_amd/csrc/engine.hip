@@ -1,0 +1,261 @@
+// engine.hip — the C-ABI of include/zkemail_amd.h over the HIP kernels in this directory.
+//
+// Host side: workspace management, kernel launches on one stream, DFA registration.  No
+// verification arithmetic runs on the host and there is no CPU fallback: without a HIP
+// device every entry point returns ZKE_E_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "zkemail_amd.h"
+#include "sha256.hip.h"
+#include "rsa.hip.h"
+#include "parse.hip.h"
+#include "regex.hip.h"
+
+using namespace zke;
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t need) {
+    if (need <= cap) return 0;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    size_t want = std::max(need + need / 4, (size_t)4096);
+    cap = 0;
+    if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return ZKE_E_NOMEM; }
+    cap = want;
+    return 0;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct RegisteredDfa {
+  bool valid = false;
+  DfaDev fwd, rev;          // device images (tables live in `blob`)
+  DevBuf blob;
+};
+
+}  // namespace
+
+struct zke_engine {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  bool timing = false;
+  zke_timings last{};
+  hipEvent_t ev[16]{};
+  // device workspace
+  DevBuf in_raw, in_raw_off, in_dom, in_dom_off, in_key, in_key_off, in_ktype, in_extnull;
+  DevBuf in_cap_off, in_cap_str_off, in_cap_blob;
+  DevBuf results, meta, rsa_jobs, sha_jobs, rsa_ok, em_dbg, scratch_off, scratch, clean, meta2;
+  DevBuf misc;   // building-block entry points
+  std::vector<RegisteredDfa*> dfas;
+  uint32_t max_sig_rounds = 2;
+};
+
+namespace {
+
+int fail(zke_engine* e, int code, const char* what, hipError_t he = hipSuccess) {
+  if (e) {
+    e->err = what;
+    if (he != hipSuccess) { e->err += ": "; e->err += hipGetErrorString(he); }
+  }
+  return code;
+}
+#define HIPCHK(e, call) do { hipError_t _r = (call); if (_r != hipSuccess) return fail((e), ZKE_E_DEVICE, #call, _r); } while (0)
+
+template <int T>
+int launch_sha(zke_engine* e, const ShaJob* jobs, uint32_t n, hipStream_t s) {
+  if (n == 0) return 0;
+  static bool attr_set = false;
+  const size_t lds = sha256_lds_bytes<T>();
+  if (!attr_set) {
+    HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&sha256_batch_kernel<T>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const uint32_t grid = (n + 255) / 256;
+  hipLaunchKernelGGL(sha256_batch_kernel<T>, dim3(grid), dim3(256), lds, s, jobs, n);
+  HIPCHK(e, hipGetLastError());
+  return 0;
+}
+
+constexpr int SHA_TILE = 256;
+
+int launch_rsa(zke_engine* e, const RsaJob* jobs, uint32_t n, const uint8_t* hash_base, size_t hash_stride,
+               uint32_t* ok, uint8_t* em, hipStream_t s, bool any_big) {
+  if (n == 0) return 0;
+  const uint32_t grid = (n + 3) / 4;
+  hipLaunchKernelGGL(rsa_verify_kernel<1>, dim3(grid), dim3(256), 0, s, jobs, n, hash_base, hash_stride, ok, em, 2048);
+  HIPCHK(e, hipGetLastError());
+  if (any_big) {
+    hipLaunchKernelGGL(rsa_verify_kernel<2>, dim3(grid), dim3(256), 0, s, jobs, n, hash_base, hash_stride, ok, em, 4096);
+    HIPCHK(e, hipGetLastError());
+  }
+  return 0;
+}
+
+}  // namespace
+
+#include "pipeline.hip.h"
+
+extern "C" {
+
+const char* zke_version(void) { return "zkemail.rs_amd 0.1 (gfx950)"; }
+
+int zke_device_available(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n > 0 ? 1 : 0;
+}
+
+int zke_engine_create(const zke_options* opt, zke_engine** out) {
+  if (!out) return ZKE_E_ARG;
+  *out = nullptr;
+  if (!zke_device_available()) return ZKE_E_DEVICE;
+  zke_engine* e = new zke_engine();
+  int dev = opt ? opt->device : -1;
+  if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+  e->device = dev;
+  if (hipSetDevice(dev) != hipSuccess) { delete e; return ZKE_E_DEVICE; }
+  if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return ZKE_E_DEVICE; }
+  for (auto& ev : e->ev) if (hipEventCreate(&ev) != hipSuccess) { delete e; return ZKE_E_DEVICE; }
+  if (opt && opt->reserved[0]) e->max_sig_rounds = std::min<uint32_t>(opt->reserved[0], 8);
+  *out = e;
+  return 0;
+}
+
+void zke_engine_destroy(zke_engine* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  (void)hipStreamSynchronize(e->stream);
+  DevBuf* bufs[] = {&e->in_raw, &e->in_raw_off, &e->in_dom, &e->in_dom_off, &e->in_key, &e->in_key_off, &e->in_ktype,
+                    &e->in_extnull, &e->in_cap_off, &e->in_cap_str_off, &e->in_cap_blob, &e->results, &e->meta,
+                    &e->rsa_jobs, &e->sha_jobs, &e->rsa_ok, &e->em_dbg, &e->scratch_off, &e->scratch, &e->clean,
+                    &e->meta2, &e->misc};
+  for (auto* b : bufs) b->release();
+  for (auto* d : e->dfas) { d->blob.release(); delete d; }
+  for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+
+const char* zke_last_error(const zke_engine* e) { return e ? e->err.c_str() : "null engine"; }
+
+int zke_engine_sync(zke_engine* e) {
+  if (!e) return ZKE_E_ARG;
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+int zke_set_timing(zke_engine* e, int enabled) {
+  if (!e) return ZKE_E_ARG;
+  e->timing = enabled != 0;
+  return 0;
+}
+
+int zke_get_timings(zke_engine* e, zke_timings* t) {
+  if (!e || !t) return ZKE_E_ARG;
+  *t = e->last;
+  return 0;
+}
+
+// ---------------------------------------------------------------- building blocks
+int zke_sha256_batch_device(zke_engine* e, const uint8_t* blob_dev, const uint64_t* off_dev, uint32_t n,
+                            uint8_t* digests_dev, void* stream) {
+  if (!e) return ZKE_E_ARG;
+  if (n == 0) return 0;
+  HIPCHK(e, hipSetDevice(e->device));
+  hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+  if (int r = e->misc.ensure((size_t)n * sizeof(ShaJob))) return fail(e, r, "workspace");
+  hipLaunchKernelGGL(sha_jobs_from_csr_kernel, dim3((n + 255) / 256), dim3(256), 0, s, blob_dev, off_dev, n, digests_dev,
+                     e->misc.as<ShaJob>());
+  HIPCHK(e, hipGetLastError());
+  return launch_sha<SHA_TILE>(e, e->misc.as<ShaJob>(), n, s);
+}
+
+int zke_sha256_batch(zke_engine* e, const uint8_t* blob, const uint64_t* off, uint32_t n, uint8_t* digests) {
+  if (!e || (n && (!blob || !off || !digests))) return ZKE_E_ARG;
+  if (n == 0) return 0;
+  HIPCHK(e, hipSetDevice(e->device));
+  const size_t total = (size_t)off[n];
+  DevBuf dblob, doff, ddig;
+  int r = 0;
+  if ((r = dblob.ensure(total + 16)) || (r = doff.ensure((size_t)(n + 1) * 8)) || (r = ddig.ensure((size_t)n * 32))) {
+    dblob.release(); doff.release(); ddig.release();
+    return fail(e, r, "hipMalloc");
+  }
+  hipError_t he = hipSuccess;
+  if (total) he = hipMemcpyAsync(dblob.p, blob, total, hipMemcpyHostToDevice, e->stream);
+  if (he == hipSuccess) he = hipMemcpyAsync(doff.p, off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, e->stream);
+  if (he == hipSuccess) {
+    r = zke_sha256_batch_device(e, dblob.as<uint8_t>(), doff.as<uint64_t>(), n, ddig.as<uint8_t>(), e->stream);
+    if (r == 0) he = hipMemcpyAsync(digests, ddig.p, (size_t)n * 32, hipMemcpyDeviceToHost, e->stream);
+  }
+  hipError_t hs = hipStreamSynchronize(e->stream);
+  dblob.release(); doff.release(); ddig.release();
+  if (r) return r;
+  if (he != hipSuccess) return fail(e, ZKE_E_DEVICE, "sha256 batch copy", he);
+  if (hs != hipSuccess) return fail(e, ZKE_E_DEVICE, "sha256 batch sync", hs);
+  return 0;
+}
+
+int zke_rsa_modexp_batch(zke_engine* e, const uint8_t* sig, const uint8_t* mod, const uint64_t* exp, uint32_t bytes,
+                         uint32_t n, uint8_t* em, uint8_t* ok) {
+  if (!e || bytes == 0 || bytes > ZKE_MAX_RSA_BYTES || (n && (!sig || !mod || !exp || !em || !ok))) return ZKE_E_ARG;
+  if (n == 0) return 0;
+  HIPCHK(e, hipSetDevice(e->device));
+  std::vector<RsaJob> jobs(n);
+  bool any_big = false;
+  for (uint32_t i = 0; i < n; i++) {
+    RsaJob& j = jobs[i];
+    memset(&j, 0, sizeof j);
+    const uint8_t* m = mod + (size_t)i * bytes;
+    const uint8_t* s = sig + (size_t)i * bytes;
+    memcpy(j.mod + 512 - bytes, m, bytes);
+    memcpy(j.sig + 512 - bytes, s, bytes);
+    uint32_t lead = 0;
+    while (lead < bytes && m[lead] == 0) lead++;
+    j.k = bytes - lead;
+    uint32_t bits = j.k * 8;
+    if (j.k) for (uint8_t t = m[lead]; !(t & 0x80); t <<= 1) bits--;
+    j.bits = bits;
+    j.e = exp[i];
+    j.sig_len = j.k;
+    j.flags = RSA_F_ACTIVE;
+    any_big |= bits > 2048;
+    ok[i] = (uint8_t)((m[bytes - 1] & 1) && bits >= 2 && memcmp(s, m, bytes) < 0);
+  }
+  DevBuf dj, dok, dem, dh;
+  int r = 0;
+  if ((r = dj.ensure(jobs.size() * sizeof(RsaJob))) || (r = dok.ensure((size_t)n * 4)) || (r = dem.ensure((size_t)n * 512)) ||
+      (r = dh.ensure((size_t)n * 32))) {
+    dj.release(); dok.release(); dem.release(); dh.release();
+    return fail(e, r, "hipMalloc");
+  }
+  hipError_t he = hipMemcpyAsync(dj.p, jobs.data(), jobs.size() * sizeof(RsaJob), hipMemcpyHostToDevice, e->stream);
+  if (he == hipSuccess) he = hipMemsetAsync(dh.p, 0, (size_t)n * 32, e->stream);
+  if (he == hipSuccess) he = hipMemsetAsync(dem.p, 0, (size_t)n * 512, e->stream);
+  if (he == hipSuccess) r = launch_rsa(e, dj.as<RsaJob>(), n, dh.as<uint8_t>(), 32, dok.as<uint32_t>(), dem.as<uint8_t>(), e->stream, any_big);
+  std::vector<uint8_t> emh((size_t)n * 512);
+  if (he == hipSuccess && r == 0) he = hipMemcpyAsync(emh.data(), dem.p, emh.size(), hipMemcpyDeviceToHost, e->stream);
+  hipError_t hs = hipStreamSynchronize(e->stream);
+  dj.release(); dok.release(); dem.release(); dh.release();
+  if (r) return r;
+  if (he != hipSuccess) return fail(e, ZKE_E_DEVICE, "rsa batch", he);
+  if (hs != hipSuccess) return fail(e, ZKE_E_DEVICE, "rsa batch sync", hs);
+  for (uint32_t i = 0; i < n; i++) memcpy(em + (size_t)i * bytes, emh.data() + (size_t)i * 512 + 512 - bytes, bytes);
+  return 0;
+}
+
+}  // extern "C"

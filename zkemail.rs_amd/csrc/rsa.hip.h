@@ -1,0 +1,288 @@
+// rsa.hip.h — RSA public-key operation + EMSA-PKCS1-v1_5 check, one signature per wavefront.
+//
+// Replaces rsa 0.9.6 (RsaPublicKey::verify with Pkcs1v15Sign::new::<Sha256>()) over
+// num-bigint-dig 0.8.4, reached through cfdkim's verify_signature; call site
+// core/src/email.rs:31-33.  RFC 8017 §8.2.2 / §9.2.
+//
+// Mapping.  A 2048-bit operand is exactly 64 x 32-bit limbs = ONE LIMB PER LANE of a
+// wave64 (NL = 1); RSA-3072/4096 take two limbs per lane (NL = 2).  Montgomery
+// multiplication runs limb-serial over b (v_readlane broadcast of b_i and of the
+// quotient digit), limb-parallel over a and n: every lane does two v_mad_u64_u32 per
+// step and keeps its column in a redundant (low word, small high word) form, so the only
+// cross-lane traffic per step is one whole-wave shift of the low words (DPP wave_shl).
+// Carries are resolved once per multiplication with the ballot carry-lookahead
+// (generate/propagate masks added as 64-bit scalars).  Pure 32/64-bit integer VALU; no
+// LDS, no MFMA.
+//
+// R^2 mod n is derived on the device per signature (no host precomputation):
+// R mod n by subtraction (+ modular doublings when the modulus does not fill its
+// container), then log2(bits) Montgomery squarings of 2R.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace zke {
+
+struct RsaJob {                 // written by the parse kernel (or the host for the unit entry point)
+  uint8_t  mod[512];            // modulus, big-endian, right-aligned in mod[512-k .. 512)
+  uint8_t  sig[512];            // signature, big-endian, right-aligned in sig[512-k .. 512)
+  uint64_t e;                   // public exponent
+  uint32_t k;                   // modulus length in bytes (minimal)
+  uint32_t flags;               // RSA_F_*
+  uint32_t bits;                // modulus bit length
+  uint32_t sig_len;             // decoded b= length in bytes
+  uint32_t pad[2];
+};
+static_assert(sizeof(RsaJob) == 1056, "RsaJob layout");
+
+enum : uint32_t {
+  RSA_F_ACTIVE = 1,             // run the modexp
+  RSA_F_LEN_MISMATCH = 2,       // sig_len != k  -> verification error without a modexp
+};
+
+// ---- cross-lane helpers -------------------------------------------------------------
+// value of lane+1 (lane 63 gets 0): v_mov_b32_dpp wave_shl:1 bound_ctrl:0
+__device__ __forceinline__ uint32_t lane_up(uint32_t x) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130 /*wave_shl:1*/, 0xf, 0xf, false);
+}
+// value of lane-1 (lane 0 gets 0): wave_shr:1
+__device__ __forceinline__ uint32_t lane_down(uint32_t x) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __ballot(p); }
+
+// A big number in "lane-major" layout: limb index = q*64 + lane for q in [0,NL).
+template <int NL> struct Big { uint32_t v[NL]; };
+
+// x >= y ?   (lexicographic from the top limb: the highest differing limb decides)
+template <int NL>
+__device__ __forceinline__ bool big_ge(const Big<NL>& x, const Big<NL>& y) {
+#pragma unroll
+  for (int q = NL - 1; q >= 0; q--) {
+    uint64_t gt = ballot64(x.v[q] > y.v[q]), lt = ballot64(x.v[q] < y.v[q]);
+    if (gt != lt) return gt > lt;
+  }
+  return true;
+}
+
+// r = x - y (mod 2^(2048*NL)); returns the borrow out.  Borrow-lookahead with ballots.
+template <int NL>
+__device__ __forceinline__ uint32_t big_sub(Big<NL>& r, const Big<NL>& x, const Big<NL>& y, int lane) {
+  uint32_t bin = 0;
+#pragma unroll
+  for (int q = 0; q < NL; q++) {
+    uint32_t d = x.v[q] - y.v[q];
+    uint64_t g = ballot64(x.v[q] < y.v[q]);        // generates a borrow
+    uint64_t p = ballot64(d == 0);                  // propagates an incoming borrow
+    // borrow into lane j = bit j of ((g<<1 | bin) + p) ^ p
+    uint64_t gs = (g << 1) | bin;
+    uint64_t sum = gs + p;
+    uint32_t carry_out = (uint32_t)((g >> 63) | ((sum < gs) ? 1u : 0u));
+    uint64_t inc = sum ^ p;
+    r.v[q] = d - (uint32_t)((inc >> lane) & 1);
+    bin = carry_out;
+  }
+  return bin;
+}
+
+// Normalise columns (lo + hi*2^32 at limb position) into 32-bit limbs; returns the overflow
+// word above the top limb.  hi is small (< 2^3).
+template <int NL>
+__device__ __forceinline__ uint32_t big_normalize(Big<NL>& r, const uint32_t (&lo)[NL], const uint32_t (&hi)[NL], int lane) {
+  uint32_t cin = 0;      // carry word from the previous 64-limb group's top lane
+  uint32_t cbit = 0;     // single-bit carry into lane 0 of this group
+#pragma unroll
+  for (int q = 0; q < NL; q++) {
+    uint32_t up = lane_down(hi[q]);                 // hi of limb-1 lands on this limb
+    if (lane == 0) up = cin;
+    uint32_t x = lo[q] + up;
+    uint64_t g = ballot64(x < up);
+    uint64_t p = ballot64(x == 0xFFFFFFFFu);
+    uint64_t gs = (g << 1) | cbit;
+    uint64_t sum = gs + p;
+    uint32_t cout = (uint32_t)((g >> 63) | ((sum < gs) ? 1u : 0u));
+    uint64_t inc = sum ^ p;
+    r.v[q] = x + (uint32_t)((inc >> lane) & 1);
+    cin = __builtin_amdgcn_readlane(hi[q], 63);
+    cbit = cout;
+  }
+  return cin + cbit;
+}
+
+// Montgomery product r = a*b*R^-1 mod n, R = 2^(2048*NL); a, b < n; n odd; ninv = -n^-1 mod 2^32.
+template <int NL>
+__device__ __forceinline__ void mont_mul(Big<NL>& r, const Big<NL>& a, const Big<NL>& b, const Big<NL>& n,
+                                         uint32_t ninv, int lane) {
+  uint32_t tl[NL], th[NL];
+#pragma unroll
+  for (int q = 0; q < NL; q++) { tl[q] = 0; th[q] = 0; }
+#pragma unroll 1
+  for (int qi = 0; qi < NL; qi++) {
+#pragma unroll 4
+    for (int i = 0; i < 64; i++) {
+      const uint32_t bi = __builtin_amdgcn_readlane(b.v[qi], i);
+      uint32_t lo[NL];
+      uint64_t H[NL];
+#pragma unroll
+      for (int q = 0; q < NL; q++) {
+        uint64_t p = (uint64_t)a.v[q] * bi + tl[q];
+        lo[q] = (uint32_t)p;
+        H[q] = (p >> 32) + th[q];
+      }
+      const uint32_t m = __builtin_amdgcn_readfirstlane(lo[0] * ninv);
+#pragma unroll
+      for (int q = 0; q < NL; q++) {
+        uint64_t p2 = (uint64_t)n.v[q] * m + lo[q];
+        lo[q] = (uint32_t)p2;
+        H[q] += (p2 >> 32);
+      }
+      // divide by 2^32: limb position l+1 becomes l.  lo[0] of lane 0 is zero by construction.
+#pragma unroll
+      for (int q = 0; q < NL; q++) {
+        uint32_t nxt = lane_up(lo[q]);
+        if (q + 1 < NL) {                                     // limb 64 (lane 0 of the next group) feeds limb 63
+          const uint32_t first = __builtin_amdgcn_readfirstlane(lo[q + 1 < NL ? q + 1 : q]);
+          if (lane == 63) nxt = first;
+        }
+        uint64_t t = H[q] + nxt;
+        tl[q] = (uint32_t)t;
+        th[q] = (uint32_t)(t >> 32);
+      }
+    }
+  }
+  Big<NL> t;
+  uint32_t top = big_normalize<NL>(t, tl, th, lane);
+  if (top || big_ge<NL>(t, n)) big_sub<NL>(r, t, n, lane); else r = t;
+}
+
+// x = 2x mod n (x < n)
+template <int NL>
+__device__ __forceinline__ void mod_double(Big<NL>& x, const Big<NL>& n, int lane) {
+  uint32_t cin = 0;
+  Big<NL> d;
+#pragma unroll
+  for (int q = 0; q < NL; q++) {
+    uint32_t below = lane_down(x.v[q]);
+    if (lane == 0) below = cin;
+    cin = __builtin_amdgcn_readlane(x.v[q], 63);
+    d.v[q] = (x.v[q] << 1) | (below >> 31);
+  }
+  uint32_t top = cin >> 31;
+  if (top || big_ge<NL>(d, n)) big_sub<NL>(x, d, n, lane); else x = d;
+}
+
+// DigestInfo prefix for SHA-256 (RFC 8017 §9.2 note 1)
+__device__ const uint8_t SHA256_DIGESTINFO[19] = {0x30, 0x31, 0x30, 0x0d, 0x06, 0x09, 0x60, 0x86, 0x48, 0x01,
+                                                  0x65, 0x03, 0x04, 0x02, 0x01, 0x05, 0x00, 0x04, 0x20};
+
+// EMSA-PKCS1-v1_5 byte at little-endian position q (q = 0 is the last byte of EM), for SHA-256:
+// EM = 0x00 0x01 FF..FF 0x00 | DigestInfo prefix | H
+__device__ __forceinline__ uint32_t emsa_byte(uint32_t q, uint32_t k, const uint32_t* hash_words) {
+  if (q >= k) return 0;
+  if (q < 32) {
+    const uint32_t bi = 31 - q;                              // byte index in the digest as stored
+    return (hash_words[bi >> 2] >> (8 * (bi & 3))) & 0xff;
+  }
+  if (q < 51) return SHA256_DIGESTINFO[18 - (q - 32)];
+  if (q == 51) return 0x00;
+  if (q == k - 1) return 0x00;
+  if (q == k - 2) return 0x01;
+  return 0xff;
+}
+
+// One wave per job.  blockDim = 256 (4 waves), grid = ceil(n/4).
+// ok_out[i]: 1 = signature verifies (EM == EMSA(hash)), 0 = not.  em_out (optional): EM big-endian, 512 B slots,
+// right-aligned like RsaJob.sig.  hash_base + i*hash_stride -> 32-byte SHA-256 of the header preimage.
+template <int NL>
+__global__ __launch_bounds__(256) void rsa_verify_kernel(const RsaJob* __restrict__ jobs, uint32_t n,
+                                                         const uint8_t* __restrict__ hash_base, size_t hash_stride,
+                                                         uint32_t* __restrict__ ok_out, uint8_t* __restrict__ em_out,
+                                                         int max_bits_this_launch) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t job = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (job >= n) return;
+  const RsaJob* J = jobs + job;
+  const uint32_t flags = J->flags, k = J->k, bits = J->bits;
+  // this launch handles moduli in (max_bits/2, max_bits]; others belong to the sibling launch
+  const bool mine = (NL == 1) ? (bits <= 2048) : (bits > 2048);
+  (void)max_bits_this_launch;
+  if (!mine) return;
+
+  Big<NL> nn, s;
+#pragma unroll
+  for (int q = 0; q < NL; q++) {
+    const uint32_t limb = q * 64 + lane;                    // little-endian limb index
+    const uint32_t boff = 512 - 4 * (limb + 1);             // its big-endian byte offset in the 512-byte field
+    nn.v[q] = __builtin_bswap32(*(const uint32_t*)(J->mod + boff));
+    s.v[q] = __builtin_bswap32(*(const uint32_t*)(J->sig + boff));
+  }
+  uint32_t ok = 0;
+  const bool odd = (__builtin_amdgcn_readfirstlane(nn.v[0]) & 1) != 0;
+  const bool lenok = !(flags & RSA_F_LEN_MISMATCH);
+  Big<NL> em;
+#pragma unroll
+  for (int q = 0; q < NL; q++) em.v[q] = 0;
+  if ((flags & RSA_F_ACTIVE) && odd && lenok && bits >= 2 && !big_ge<NL>(s, nn)) {
+    // ninv = -n^-1 mod 2^32 (Newton; n odd)
+    uint32_t n0 = __builtin_amdgcn_readfirstlane(nn.v[0]);
+    uint32_t x = n0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) x *= 2 - n0 * x;
+    const uint32_t ninv = 0u - x;
+    // one = R mod n.  2^bits - n, then double (container_bits - bits) times.
+    Big<NL> one;
+    {
+      Big<NL> pw;                                            // 2^bits mod 2^container (0 when bits == container)
+#pragma unroll
+      for (int q = 0; q < NL; q++) {
+        const uint32_t limb = q * 64 + lane;
+        pw.v[q] = (bits < 2048u * NL && (bits >> 5) == limb) ? (1u << (bits & 31)) : 0u;
+      }
+      big_sub<NL>(one, pw, nn, lane);                        // 2^bits - n  (mod 2^container): in [1, n)
+      for (uint32_t i = bits; i < 2048u * NL; i++) mod_double<NL>(one, nn, lane);
+    }
+    Big<NL> rr = one;
+    mod_double<NL>(rr, nn, lane);                            // 2R mod n
+    // (2R)^(2^t) in the Montgomery domain = 2^(2^t) R; t = log2(container bits) -> R*R = R^2 mod n
+    constexpr int T = (NL == 1) ? 11 : 12;
+#pragma unroll 1
+    for (int i = 0; i < T; i++) mont_mul<NL>(rr, rr, rr, nn, ninv, lane);
+    Big<NL> xm;
+    mont_mul<NL>(xm, s, rr, nn, ninv, lane);                 // s in Montgomery form
+    Big<NL> acc = xm;
+    const uint64_t e = J->e | (J->e == 0);                   // e >= 1 (key decode enforces 2 <= e < 2^33)
+    const int top = 63 - __builtin_clzll(e);
+#pragma unroll 1
+    for (int bit = top - 1; bit >= 0; bit--) {
+      mont_mul<NL>(acc, acc, acc, nn, ninv, lane);
+      if ((e >> bit) & 1) mont_mul<NL>(acc, acc, xm, nn, ninv, lane);
+    }
+    Big<NL> lit;
+#pragma unroll
+    for (int q = 0; q < NL; q++) lit.v[q] = (q == 0 && lane == 0) ? 1u : 0u;
+    mont_mul<NL>(em, acc, lit, nn, ninv, lane);              // out of the Montgomery domain
+    // EMSA-PKCS1-v1_5 compare (rsa 0.9.6 pkcs1v15_sign_unpad); needs k >= 19 + 32 + 11
+    const uint32_t* hw = (const uint32_t*)(hash_base + (size_t)job * hash_stride);
+    bool match = k >= 62;
+#pragma unroll
+    for (int q = 0; q < NL; q++) {
+      const uint32_t limb = q * 64 + lane;
+      uint32_t expect = 0;
+#pragma unroll
+      for (int b = 0; b < 4; b++) expect |= emsa_byte(4 * limb + b, k, hw) << (8 * b);
+      match = match && (ballot64(em.v[q] != expect) == 0);
+    }
+    ok = match ? 1u : 0u;
+  }
+  if (lane == 0) ok_out[job] = ok;
+  if (em_out) {
+#pragma unroll
+    for (int q = 0; q < NL; q++) {
+      const uint32_t limb = q * 64 + lane;
+      *(uint32_t*)(em_out + (size_t)job * 512 + 512 - 4 * (limb + 1)) = __builtin_bswap32(em.v[q]);
+    }
+    if (NL == 1) *(uint32_t*)(em_out + (size_t)job * 512 + 4 * lane) = 0;   // upper half of the slot
+  }
+}
+
+}  // namespace zke

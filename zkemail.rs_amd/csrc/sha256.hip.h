@@ -1,0 +1,174 @@
+// sha256.hip.h — batched SHA-256 for gfx950 (CDNA4).  FIPS 180-4.
+//
+// Replaces sha2 0.10.9 on the verify path: hash_bytes (core/src/crypto.rs:3-7, used at
+// core/src/circuits.rs:16-17) and the body / header hashes inside cfdkim
+// (call site core/src/email.rs:31-33).
+//
+// Mapping.  SHA-256 is a strictly sequential chain per message, so parallelism comes
+// from the batch: ONE MESSAGE PER LANE for the compression (64 messages per wavefront,
+// all 64 lanes doing integer VALU work), while the bytes are fetched WAVE-COOPERATIVELY:
+// for each tile of T bytes the 64 lanes read each message's tile with 16-byte
+// lane-contiguous global loads (T/16 lanes cover one message's tile -> 256-byte
+// contiguous segments at T=256), park it in the wave's private LDS slab, and every lane
+// then pulls its own message's 64-byte blocks back with ds_read_b128.  Row stride T+16
+// bytes keeps both the ds_write_b128 and the ds_read_b128 phases conflict-free
+// (lane stride = 4 banks mod 64).  No __syncthreads: a wave's LDS operations execute in
+// order, and no other wave touches its slab.
+//
+// Roofline: integer-VALU bound (about 1.5k VALU per 64-byte block per lane), not HBM
+// bound; DESIGN.md §kernels has the arithmetic.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace zke {
+
+struct ShaJob {          // one message
+  uint64_t src;          // device address of the bytes
+  uint64_t dst;          // device address of the 32-byte digest
+  uint32_t len;          // bytes
+  uint32_t pad;
+};
+
+__device__ __forceinline__ uint32_t rotr32(uint32_t x, int n) { return __builtin_amdgcn_alignbit(x, x, n); }
+// gfx950 v_bitop3_b32: any 3-input boolean function in one VALU op (truth table in the immediate)
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+__device__ __forceinline__ uint32_t ch3(uint32_t e, uint32_t f, uint32_t g) { return __builtin_amdgcn_bitop3_b32(e, f, g, 0xCA); }   // e ? f : g
+__device__ __forceinline__ uint32_t maj3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8); }
+
+// One compression.  w[16] holds the big-endian message words and is consumed.
+// The round constants are compile-time literals after full unrolling (no loads).
+__device__ __forceinline__ void sha256_compress(uint32_t (&st)[8], uint32_t (&w)[16]) {
+  constexpr uint32_t K[64] = {
+      0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
+      0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+      0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+      0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+      0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+      0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+      0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
+      0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+  uint32_t a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+#pragma unroll
+  for (int i = 0; i < 64; i++) {
+    uint32_t wi;
+    if (i < 16) {
+      wi = w[i];
+    } else {
+      uint32_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
+      uint32_t s0 = xor3(rotr32(w15, 7), rotr32(w15, 18), w15 >> 3);
+      uint32_t s1 = xor3(rotr32(w2, 17), rotr32(w2, 19), w2 >> 10);
+      wi = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
+      w[i & 15] = wi;
+    }
+    uint32_t S1 = xor3(rotr32(e, 6), rotr32(e, 11), rotr32(e, 25));
+    uint32_t t1 = (h + S1 + ch3(e, f, g)) + (K[i] + wi);
+    uint32_t S0 = xor3(rotr32(a, 2), rotr32(a, 13), rotr32(a, 22));
+    uint32_t mj = maj3(a, b, c);
+    h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + S0 + mj;
+  }
+  st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
+}
+
+typedef uint4 __attribute__((aligned(1))) uint4_unaligned;
+
+// Launch: blockDim = 256 (4 independent waves), grid = ceil(n / 256).
+// LDS: 4 waves * 64 rows * (T + 16) bytes  (T = 256 -> 69,632 B per block).
+template <int T>
+__global__ __launch_bounds__(256) void sha256_batch_kernel(const ShaJob* __restrict__ jobs, uint32_t n) {
+  static_assert(T % 64 == 0 && T >= 64 && T <= 1024, "tile must be whole SHA blocks");
+  constexpr int ROW = T + 16;            // bytes
+  constexpr int LPR = T / 16;            // lanes that cover one row's tile
+  constexpr int RPI = 64 / LPR;          // rows per load instruction
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  uint8_t* slab = lds_raw + (size_t)wave * (64 * ROW + 64 * 16);
+  uint8_t* desc = slab + 64 * ROW;       // 64 x {src(8), len(4), pad(4)}
+
+  const uint32_t m = (blockIdx.x * 4 + wave) * 64 + lane;
+  uint64_t my_src = 0, my_dst = 0;
+  uint32_t my_len = 0, my_nblk = 0;
+  if (m < n) {
+    ShaJob j = jobs[m];
+    my_src = j.src; my_dst = j.dst; my_len = j.len;
+    my_nblk = (my_len + 9 + 63) >> 6;
+  }
+  *(uint64_t*)(desc + lane * 16) = my_src;
+  *(uint32_t*)(desc + lane * 16 + 8) = my_len;
+  *(uint32_t*)(desc + lane * 16 + 12) = my_nblk;
+  uint32_t max_nblk = my_nblk;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) max_nblk = max(max_nblk, (uint32_t)__shfl_xor((int)max_nblk, o));
+  max_nblk = __builtin_amdgcn_readfirstlane(max_nblk);
+
+  uint32_t st[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+  uint8_t* my_row = slab + lane * ROW;
+
+  for (uint32_t blk0 = 0; blk0 < max_nblk; blk0 += T / 64) {
+    const uint32_t tile_off = blk0 * 64;
+    // ---- cooperative fill: RPI rows per instruction, 16 B per lane
+#pragma unroll 4
+    for (int g = 0; g < LPR; g++) {
+      const int row = g * RPI + lane / LPR;
+      const int chunk = lane % LPR;
+      const uint64_t rsrc = *(const uint64_t*)(desc + row * 16);
+      const uint32_t rlen = *(const uint32_t*)(desc + row * 16 + 8);
+      const uint32_t rnblk = *(const uint32_t*)(desc + row * 16 + 12);
+      const uint32_t off = tile_off + chunk * 16;
+      if (blk0 < rnblk) {                      // rows that are already finished are skipped
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (off + 16 <= rlen) {
+          v = *(const uint4_unaligned*)(rsrc + off);
+        } else if (off < rlen) {               // last partial chunk of the message: byte loads, never past the end
+          const uint8_t* p = (const uint8_t*)(rsrc + off);
+          uint32_t rem = rlen - off, t[4] = {0, 0, 0, 0};
+          for (uint32_t b = 0; b < rem; b++) t[b >> 2] |= (uint32_t)p[b] << (8 * (b & 3));
+          v = make_uint4(t[0], t[1], t[2], t[3]);
+        }
+        *(uint4*)(slab + row * ROW + chunk * 16) = v;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- padding, patched into the lane's own row (FIPS 180-4 §5.1.1)
+    if (blk0 < my_nblk) {
+      if (my_len >= tile_off && my_len < tile_off + T) my_row[my_len - tile_off] = 0x80;
+      const uint32_t last = my_nblk - 1;
+      if (last >= blk0 && last < blk0 + T / 64) {
+        const uint64_t bits = (uint64_t)my_len * 8;
+        uint32_t* tail = (uint32_t*)(my_row + (last - blk0) * 64 + 56);
+        tail[0] = __builtin_bswap32((uint32_t)(bits >> 32));
+        tail[1] = __builtin_bswap32((uint32_t)bits);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- compress: one message per lane
+#pragma unroll 1
+    for (int b = 0; b < T / 64; b++) {
+      if (blk0 + b < my_nblk) {
+        uint32_t w[16];
+        const uint4* src = (const uint4*)(my_row + b * 64);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          uint4 v = src[q];
+          w[4 * q + 0] = __builtin_bswap32(v.x); w[4 * q + 1] = __builtin_bswap32(v.y);
+          w[4 * q + 2] = __builtin_bswap32(v.z); w[4 * q + 3] = __builtin_bswap32(v.w);
+        }
+        sha256_compress(st, w);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (m < n) {
+    uint32_t* out = (uint32_t*)my_dst;      // digests are 4-byte aligned (result records / engine buffers)
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[i] = __builtin_bswap32(st[i]);
+  }
+}
+
+template <int T>
+constexpr size_t sha256_lds_bytes() { return 4 * (64 * (T + 16) + 64 * 16); }
+
+}  // namespace zke
