@@ -85,11 +85,16 @@ enum {
   /* regex */
   ZKE_D_RE_MATCH_COUNT       = 60, /* find_iter(..).count() != 1      core/src/regex.rs:37 */
   ZKE_D_RE_CAPTURE_MISSING   = 61, /* !matched_str.contains(capture)  core/src/regex.rs:44 */
-  ZKE_D_RE_QUIT              = 62  /* DFA entered its quit state (find_iter panics in the reference) */
+  ZKE_D_RE_QUIT              = 62, /* DFA entered its quit state (find_iter panics in the reference) */
+  /* ZKE_UNSUPPORTED, continued */
+  ZKE_D_U_SIG_TOO_LONG       = 63, /* FWS-stripped tag values of one DKIM-Signature exceed ZKE_MAX_TAGBUF bytes */
+  ZKE_D_U_TOO_MANY_SIGS      = 64, /* more failing same-domain signatures than the engine's signature rounds */
+  ZKE_D_U_SIG_B_REPEATED     = 65  /* the raw b= value occurs more than once in its header (reference removes every occurrence) */
 };
 
 #define ZKE_MAX_HEADERS 512u   /* header fields per email the device parser tables hold */
 #define ZKE_MAX_TAGS    32u    /* tag-specs per DKIM-Signature */
+#define ZKE_MAX_TAGBUF  2048u  /* bytes of FWS-stripped tag values per DKIM-Signature */
 #define ZKE_MAX_RSA_BYTES 512u /* RSA-4096, the rsa crate's ceiling (rsa 0.9.6 RsaPublicKey::MAX_SIZE) */
 #define ZKE_KEY_RSA 0u
 #define ZKE_KEY_ED25519 1u

@@ -70,6 +70,9 @@ D_U_EMAIL_TOO_LARGE = 58
 D_RE_MATCH_COUNT = 60
 D_RE_CAPTURE_MISSING = 61
 D_RE_QUIT = 62
+D_U_SIG_TOO_LONG = 63
+D_U_TOO_MANY_SIGS = 64
+D_U_SIG_B_REPEATED = 65
 
 KEY_RSA, KEY_ED25519, KEY_OTHER = 0, 1, 2
 F_HDR_RELAXED, F_BODY_RELAXED, F_HAS_LENGTH = 1, 2, 4

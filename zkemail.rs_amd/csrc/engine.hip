@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -40,10 +41,13 @@ struct DevBuf {
 };
 
 struct RegisteredDfa {
-  bool valid = false;
-  DfaDev fwd, rev;          // device images (tables live in `blob`)
-  DevBuf blob;
+  bool valid = false;       // both blobs deserialise (dense::DFA::from_bytes would succeed)
+  size_t lds_bytes = 0;     // repacked fwd + rev tables
+  DevBuf blob;              // the repacked tables
+  DevBuf dev;               // RegexDev image
 };
+
+inline uint32_t e_k(uint32_t bits) { return (bits + 7) / 8; }
 
 }  // namespace
 
@@ -54,10 +58,15 @@ struct zke_engine {
   bool timing = false;
   zke_timings last{};
   hipEvent_t ev[16]{};
+  hipEvent_t ev_h2d[4]{};
+  int timed_marks = 0;
+  bool timed_regex = false;
+  size_t dfa_lds_attr = 0;
+  std::vector<uint32_t> host_hdr_ids, host_body_ids;
   // device workspace
   DevBuf in_raw, in_raw_off, in_dom, in_dom_off, in_key, in_key_off, in_ktype, in_extnull;
   DevBuf in_cap_off, in_cap_str_off, in_cap_blob;
-  DevBuf results, meta, rsa_jobs, sha_jobs, rsa_ok, em_dbg, scratch_off, scratch, clean, meta2;
+  DevBuf results, meta, rsa_jobs, sha_jobs, rsa_ok, em_dbg, scratch_off, scratch, clean, meta2, scratch2, parts;
   DevBuf misc;   // building-block entry points
   std::vector<RegisteredDfa*> dfas;
   uint32_t max_sig_rounds = 2;
@@ -130,6 +139,7 @@ int zke_engine_create(const zke_options* opt, zke_engine** out) {
   if (hipSetDevice(dev) != hipSuccess) { delete e; return ZKE_E_DEVICE; }
   if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return ZKE_E_DEVICE; }
   for (auto& ev : e->ev) if (hipEventCreate(&ev) != hipSuccess) { delete e; return ZKE_E_DEVICE; }
+  for (auto& ev : e->ev_h2d) if (hipEventCreate(&ev) != hipSuccess) { delete e; return ZKE_E_DEVICE; }
   if (opt && opt->reserved[0]) e->max_sig_rounds = std::min<uint32_t>(opt->reserved[0], 8);
   *out = e;
   return 0;
@@ -142,10 +152,11 @@ void zke_engine_destroy(zke_engine* e) {
   DevBuf* bufs[] = {&e->in_raw, &e->in_raw_off, &e->in_dom, &e->in_dom_off, &e->in_key, &e->in_key_off, &e->in_ktype,
                     &e->in_extnull, &e->in_cap_off, &e->in_cap_str_off, &e->in_cap_blob, &e->results, &e->meta,
                     &e->rsa_jobs, &e->sha_jobs, &e->rsa_ok, &e->em_dbg, &e->scratch_off, &e->scratch, &e->clean,
-                    &e->meta2, &e->misc};
+                    &e->meta2, &e->misc, &e->scratch2, &e->parts};
   for (auto* b : bufs) b->release();
-  for (auto* d : e->dfas) { d->blob.release(); delete d; }
+  for (auto* d : e->dfas) { d->blob.release(); d->dev.release(); delete d; }
   for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
+  for (auto& ev : e->ev_h2d) if (ev) (void)hipEventDestroy(ev);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }

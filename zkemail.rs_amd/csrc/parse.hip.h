@@ -1,9 +1,844 @@
+// parse.hip.h — device-side restatement of the e-mail front end of verify_dkim, one e-mail per
+// wavefront (blockDim = 64).
+//
+// Replaces, on the verify path (call sites core/src/email.rs:26-33, core/src/circuits.rs:34-35):
+//   * mailparse 0.15.0 parse_headers / parse_header (header list; the MIME subpart walk has no
+//     effect on this path other than extra parse errors on malformed subparts — not restated);
+//   * cfdkim validate_header, the tag-list grammar (RFC 6376 §3.2), d= / i= / h= / q= / v= checks,
+//     c= / a= / l= parsing, header selection (§5.4.2, bottom-up) and header canonicalisation
+//     (§3.4.1 / §3.4.2) producing the header-hash preimage (§3.7);
+//   * rsa 0.9.6 RsaPublicKey::from_pkcs1_der + check_public (RFC 8017 A.1.1);
+//   * base64 STANDARD decode of b=.
+//
+// Execution model.  Control flow is wave-uniform (one e-mail, one parser state); the 64 lanes
+// are used as a 64-byte-wide scanner: each primitive looks at 64 consecutive bytes at once and
+// turns per-byte predicates into 64-bit ballot masks (find first / find last / stream
+// compaction by popcount prefix).  Header fields are small (≈1 KB per e-mail) and are read
+// straight from HBM through L2/L1; the per-e-mail tables (header spans, tag records, the
+// FWS-stripped tag values) live in LDS.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include "zkemail_amd.h"
+#include "rsa.hip.h"
 #include "sha256.hip.h"
+
 namespace zke {
-// CSR (blob, off[n+1]) -> ShaJob list with digests packed 32 B apart
+
+constexpr uint32_t OOB = 0x100;       // "no byte here"
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+constexpr uint32_t WNONE = 0x80000000u;   // "no window loaded" (e-mails are < 2^31 bytes)
+
+// Per-e-mail state shared by the kernels of one batch.
+struct EmailMeta {
+  uint32_t state;             // ST_*
+  uint32_t status, detail;    // decided status when state == ST_FINAL
+  uint32_t unsupported;       // last ZKE_D_U_* seen on a signature (0 = none)
+  uint32_t last_touched_sig;  // oracle's sig_index when nothing passes
+  uint32_t cand_total;        // same-domain signatures that reach the hash stage
+  uint32_t cand_sig_index;    // signature index (file order) of this round's candidate
+  uint32_t cand_hdr;          // header index of this round's candidate
+  uint32_t cand_err;          // failure recorded for this round's candidate (finalize)
+  uint32_t post_err;          // last non-candidate error located after this round's candidate
+  uint32_t pre_err;           // last non-candidate error overall (used when there is no candidate)
+  uint32_t flags;             // ZKE_F_*
+  uint32_t len_tag_lo, len_tag_hi;
+  uint32_t preimage_len;
+  uint32_t body_off, body_len;
+  uint32_t canon_full_len;    // canonical body length before l=
+  uint32_t hashed_len;        // after l=
+  uint32_t body_src_is_raw;   // simple canonicalisation hashes the raw bytes in place
+  uint32_t n_headers, n_sigs;
+  uint32_t first_sig_hdr;     // header index of the first DKIM-Signature (canonicalize_signed_email)
+  uint32_t sig_b64_ok;
+  uint32_t bh_len;
+  uint8_t  bh[48];            // FWS-stripped bh= (first 48 chars)
+  uint32_t key_ok;            // RSA key decoded
+  uint32_t even_modulus;
+  uint32_t reuse;             // mode 1: the first DKIM-Signature is the verified one; scratch of the verify pass is reused
+  uint32_t pad[2];
+};
+static_assert(sizeof(EmailMeta) % 8 == 0, "EmailMeta alignment");
+
+enum : uint32_t { ST_FINAL = 0, ST_CAND = 1, ST_PENDING = 2 };
+enum : int { TG_V = 0, TG_A, TG_B, TG_BH, TG_D, TG_H, TG_S, TG_I, TG_Q, TG_C, TG_L, TG_N };
+
+// Batch view handed to the kernels (device pointers).
+struct BatchDev {
+  uint32_t n;
+  const uint8_t* raw; const uint64_t* raw_off;
+  const uint8_t* dom; const uint64_t* dom_off;
+  const uint8_t* key; const uint64_t* key_off;
+  const uint8_t* key_type; const uint8_t* ext_null;
+  zke_result* results;
+  EmailMeta* meta;
+  RsaJob* rsa;
+  ShaJob* sha;                // kind-major: sha[kind * n_pad + i], kinds 0 body, 1 header, 2 domain, 3 key
+  uint32_t n_pad;
+  uint8_t* scratch;           // per e-mail: region A (preimage) then region B (canonical body)
+  const uint64_t* scratch_off;// [n+1]; region A = raw_len + PRE_SLACK bytes, region B = raw_len + 16
+  const EmailMeta* meta_verify; // mode 1 only: the verify pass's meta
+};
+constexpr uint32_t PRE_SLACK = 1024;
+
+// ------------------------------------------------------------------ byte strings and windows
+struct Str {                  // logical string over global memory with one optional excision
+  const uint8_t* base;
+  uint32_t len;               // logical length
+  uint32_t cut, skip;         // logical index >= cut reads base[index + skip]
+};
+__device__ __forceinline__ Str mkstr(const uint8_t* b, uint32_t len) { return Str{b, len, NONE, 0}; }
+__device__ __forceinline__ uint32_t ldb(const Str& s, uint32_t l) {
+  return l < s.len ? (uint32_t)s.base[l + (l >= s.cut ? s.skip : 0u)] : OOB;
+}
+struct Win { uint32_t wpos; uint32_t c; };   // c = byte at logical wpos + lane (OOB beyond the end)
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ void wload(const Str& s, Win& w, uint32_t pos) { w.wpos = pos; w.c = ldb(s, pos + lane_id()); }
+__device__ __forceinline__ uint32_t at(const Str& s, Win& w, uint32_t pos) {   // uniform pos -> uniform byte
+  if (pos - w.wpos >= 64u) wload(s, w, pos);
+  return __builtin_amdgcn_readlane(w.c, pos - w.wpos);
+}
+__device__ __forceinline__ uint64_t bits_from(uint32_t rel) { return rel >= 64 ? 0ull : (~0ull << rel); }
+__device__ __forceinline__ uint64_t bits_below(uint32_t rel) { return rel >= 64 ? ~0ull : ((1ull << rel) - 1); }
+
+// first l in [pos, end) with pred(byte), else end
+template <class P>
+__device__ __forceinline__ uint32_t wfind(const Str& s, Win& w, uint32_t pos, uint32_t end, P pred) {
+  while (pos < end) {
+    if (pos - w.wpos >= 64u) wload(s, w, pos);
+    const uint32_t rel = pos - w.wpos;
+    uint64_t m = __ballot(pred(w.c) && (w.wpos + lane_id()) < end) & bits_from(rel);
+    if (m) return w.wpos + (uint32_t)__builtin_ctzll(m);
+    pos = w.wpos + 64;
+  }
+  return end;
+}
+// last l in [start, end) with pred(byte), else NONE
+template <class P>
+__device__ __forceinline__ uint32_t wrfind(const Str& s, Win& w, uint32_t start, uint32_t end, P pred) {
+  uint32_t pos = end;
+  while (pos > start) {
+    const uint32_t ws = (pos - start > 64u) ? pos - 64u : start;
+    if (!(ws >= w.wpos && pos <= w.wpos + 64u)) wload(s, w, ws);
+    const uint32_t l = w.wpos + lane_id();
+    uint64_t m = __ballot(pred(w.c) && l >= ws && l < pos);
+    if (m) return w.wpos + 63u - (uint32_t)__builtin_clzll(m);
+    pos = ws;
+  }
+  return NONE;
+}
+
+__device__ __forceinline__ bool is_fws(uint32_t c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n'; }
+__device__ __forceinline__ bool is_wsp(uint32_t c) { return c == ' ' || c == '\t'; }
+__device__ __forceinline__ bool is_valchar(uint32_t c) { return (c >= 0x21 && c <= 0x3a) || (c >= 0x3c && c <= 0x7e); }
+__device__ __forceinline__ bool is_alpha(uint32_t c) { return ((c | 0x20) >= 'a' && (c | 0x20) <= 'z') && c < 0x80; }
+__device__ __forceinline__ bool is_alnumpunc(uint32_t c) { return is_alpha(c) || (c >= '0' && c <= '9') || c == '_'; }
+__device__ __forceinline__ uint32_t lower(uint32_t c) { return (c >= 'A' && c <= 'Z') ? c + 32 : c; }
+
+// case-insensitive equality of s[a, a+n) with a byte string in LDS / constant / global memory
+__device__ __forceinline__ bool span_ieq(const Str& s, uint32_t a, uint32_t n, const uint8_t* name, uint32_t nlen) {
+  if (n != nlen) return false;
+  for (uint32_t o = 0; o < n; o += 64) {
+    const uint32_t l = o + lane_id();
+    bool bad = false;
+    if (l < n) bad = lower(ldb(s, a + l)) != lower(name[l]);
+    if (__ballot(bad)) return false;
+  }
+  return true;
+}
+
+// ------------------------------------------------------------------ output stream (preimage)
+struct Out { uint8_t* p; uint32_t o, cap; bool overflow; };
+__device__ __forceinline__ void emit_lit(Out& out, const char* lit, uint32_t n) {
+  if (out.o + n > out.cap) { out.overflow = true; return; }
+  if ((uint32_t)lane_id() < n) out.p[out.o + lane_id()] = (uint8_t)lit[lane_id()];
+  out.o += n;
+}
+template <class F>   // copy s[a,b) through a byte map
+__device__ __forceinline__ void emit_map(Out& out, const Str& s, uint32_t a, uint32_t b, F f) {
+  if (b <= a) return;
+  if (out.o + (b - a) > out.cap) { out.overflow = true; return; }
+  for (uint32_t l = a + lane_id(); l < b; l += 64) out.p[out.o + (l - a)] = (uint8_t)f(ldb(s, l));
+  out.o += b - a;
+}
+
+// cfdkim canonicalize_header_relaxed value part: unfold (drop CRLF), WSP runs -> one SP, trim both ends
+__device__ __forceinline__ void emit_relaxed_value(Out& out, const Str& v) {
+  const uint32_t L = v.len;
+  // last kept non-WSP byte
+  uint32_t last_nw = NONE;
+  for (uint32_t hi = L; hi > 0 && last_nw == NONE;) {
+    const uint32_t lo = hi > 64 ? hi - 64 : 0;
+    const uint32_t l = lo + lane_id();
+    bool k = false;
+    if (l < hi) {
+      const uint32_t cc = ldb(v, l), cp = l ? ldb(v, l - 1) : OOB, cn = ldb(v, l + 1);
+      const bool crlf = (cc == '\r' && cn == '\n') || (cc == '\n' && cp == '\r');
+      k = !crlf && !is_wsp(cc);
+    }
+    const uint64_t m = __ballot(k);
+    if (m) last_nw = lo + 63u - (uint32_t)__builtin_clzll(m);
+    hi = lo;
+  }
+  if (last_nw == NONE) return;
+  bool carry_wsp = true;     // "previous kept byte was WSP": true at the start trims the front
+  for (uint32_t base = 0; base <= last_nw; base += 64) {
+    const uint32_t l = base + lane_id();
+    const uint32_t cc = ldb(v, l), cp = l ? ldb(v, l - 1) : OOB, cn = ldb(v, l + 1);
+    const bool inr = l <= last_nw;
+    const bool crlf = (cc == '\r' && cn == '\n') || (cc == '\n' && cp == '\r');
+    const bool kept1 = inr && !crlf;
+    const bool wsp = is_wsp(cc);
+    const uint64_t K1 = __ballot(kept1), Wm = __ballot(kept1 && wsp);
+    const uint64_t lowerK = K1 & bits_below(lane_id());
+    bool prevw = carry_wsp;
+    if (lowerK) prevw = (Wm >> (63 - __builtin_clzll(lowerK))) & 1;
+    const bool emit = kept1 && (!wsp || !prevw);
+    const uint64_t E = __ballot(emit);
+    const uint32_t cnt = (uint32_t)__builtin_popcountll(E);
+    if (out.o + cnt > out.cap) { out.overflow = true; return; }
+    if (emit) out.p[out.o + (uint32_t)__builtin_popcountll(E & bits_below(lane_id()))] = wsp ? (uint8_t)' ' : (uint8_t)cc;
+    out.o += cnt;
+    if (K1) carry_wsp = (Wm >> (63 - __builtin_clzll(K1))) & 1;
+  }
+}
+
+// cfdkim canonicalize_header_{relaxed,simple}(key, value); the CRLF is appended by the caller's choice
+__device__ __forceinline__ void emit_header(Out& out, const Str& key, const Str& val, bool relaxed, bool crlf) {
+  if (relaxed) {
+    Win w; w.wpos = WNONE; w.c = 0;
+    uint32_t ke = wrfind(key, w, 0, key.len, [](uint32_t c) { return !is_wsp(c); });
+    ke = (ke == NONE) ? 0 : ke + 1;
+    emit_map(out, key, 0, ke, [](uint32_t c) { return lower(c); });
+    emit_lit(out, ":", 1);
+    emit_relaxed_value(out, val);
+  } else {
+    emit_map(out, key, 0, key.len, [](uint32_t c) { return c; });
+    emit_lit(out, ": ", 2);
+    emit_map(out, val, 0, val.len, [](uint32_t c) { return c; });
+  }
+  if (crlf) emit_lit(out, "\r\n", 2);
+}
+
+// ------------------------------------------------------------------ LDS image of one wave
+struct ParseLds {
+  uint32_t hdr[4 * ZKE_MAX_HEADERS];   // key_start, key_end, val_start, val_end
+  uint32_t tag[TG_N][4];               // raw_s, raw_e, val_off, val_len (last occurrence wins, as IndexMap::insert)
+  uint8_t tagbuf[ZKE_MAX_TAGBUF];      // FWS-stripped tag values
+};
+
+// strip FWS from v[rs,re) into tagbuf at *tb; returns false on overflow
+__device__ __forceinline__ bool strip_to_lds(ParseLds& L, const Str& v, uint32_t rs, uint32_t re, uint32_t& tb) {
+  for (uint32_t base = rs; base < re; base += 64) {
+    const uint32_t l = base + lane_id();
+    const uint32_t c = l < re ? ldb(v, l) : OOB;
+    const bool k = l < re && !is_fws(c);
+    const uint64_t m = __ballot(k);
+    const uint32_t cnt = (uint32_t)__builtin_popcountll(m);
+    if (tb + cnt > ZKE_MAX_TAGBUF) return false;
+    if (k) L.tagbuf[tb + (uint32_t)__builtin_popcountll(m & bits_below(lane_id()))] = (uint8_t)c;
+    tb += cnt;
+  }
+  return true;
+}
+__device__ __forceinline__ bool tagval_eq(const ParseLds& L, int id, const char* lit, uint32_t n) {
+  if (L.tag[id][3] != n) return false;
+  bool bad = false;
+  if ((uint32_t)lane_id() < n) bad = L.tagbuf[L.tag[id][2] + lane_id()] != (uint8_t)lit[lane_id()];
+  return __ballot(bad) == 0;
+}
+
+// tag-spec = [FWS] tag-name [FWS] "=" [FWS] tag-value [FWS]   (cfdkim parser::tag_spec)
+// returns the position after the spec, or NONE.  err: 0 ok, else ZKE_D_U_*
+__device__ __forceinline__ uint32_t parse_tag_spec(ParseLds& L, const Str& v, Win& w, uint32_t pos, uint32_t& present,
+                                                   uint32_t& ntags, uint32_t& tb, uint32_t& err) {
+  const uint32_t n = v.len;
+  uint32_t p = wfind(v, w, pos, n, [](uint32_t c) { return !is_fws(c); });
+  if (p >= n || !is_alpha(at(v, w, p))) return NONE;
+  const uint32_t ns = p;
+  const uint32_t ne = wfind(v, w, p, n, [](uint32_t c) { return !is_alnumpunc(c); });
+  p = wfind(v, w, ne, n, [](uint32_t c) { return !is_fws(c); });
+  if (p >= n || at(v, w, p) != '=') return NONE;
+  const uint32_t rs = wfind(v, w, p + 1, n, [](uint32_t c) { return !is_fws(c); });
+  const uint32_t rend = wfind(v, w, rs, n, [](uint32_t c) { return !(is_valchar(c) || is_fws(c)); });
+  uint32_t re = wrfind(v, w, rs, rend, [](uint32_t c) { return is_valchar(c); });
+  re = (re == NONE) ? rs : re + 1;
+  ntags++;
+  if (ntags > ZKE_MAX_TAGS) { err = ZKE_D_U_TOO_MANY_TAGS; return rend; }
+  // classify the name (case-sensitive, exact)
+  int id = -1;
+  const uint32_t c0 = at(v, w, ns);
+  if (ne - ns == 1) {
+    switch (c0) {
+      case 'v': id = TG_V; break; case 'a': id = TG_A; break; case 'b': id = TG_B; break; case 'd': id = TG_D; break;
+      case 'h': id = TG_H; break; case 's': id = TG_S; break; case 'i': id = TG_I; break; case 'q': id = TG_Q; break;
+      case 'c': id = TG_C; break; case 'l': id = TG_L; break; default: break;
+    }
+  } else if (ne - ns == 2 && c0 == 'b' && at(v, w, ns + 1) == 'h') {
+    id = TG_BH;
+  }
+  const uint32_t off = tb;
+  if (!strip_to_lds(L, v, rs, re, tb)) { err = ZKE_D_U_SIG_TOO_LONG; return rend; }
+  if (id >= 0) {
+    if (lane_id() == 0) { L.tag[id][0] = rs; L.tag[id][1] = re; L.tag[id][2] = off; L.tag[id][3] = tb - off; }
+    present |= 1u << id;
+  }
+  return rend;
+}
+
+// cfdkim validate_header over the header value v.  0 = valid, else ZKE_D_*
+__device__ __forceinline__ uint32_t validate_sig(ParseLds& L, const Str& v, uint32_t& present) {
+  Win w; w.wpos = WNONE; w.c = 0;
+  uint32_t ntags = 0, tb = 0, err = 0;
+  present = 0;
+  uint32_t p = parse_tag_spec(L, v, w, 0, present, ntags, tb, err);
+  if (p == NONE) return ZKE_D_SIG_SYNTAX;
+  while (!err && p < v.len && at(v, w, p) == ';') {
+    const uint32_t q = parse_tag_spec(L, v, w, p + 1, present, ntags, tb, err);
+    if (q == NONE) break;
+    p = q;
+  }
+  if (err) return err;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t req = (1u << TG_V) | (1u << TG_A) | (1u << TG_B) | (1u << TG_BH) | (1u << TG_D) | (1u << TG_H) | (1u << TG_S);
+  if ((present & req) != req) return ZKE_D_MISSING_TAG;
+  if (!tagval_eq(L, TG_V, "1", 1)) return ZKE_D_INCOMPATIBLE_VERSION;
+  if (present & (1u << TG_I)) {   // user.ends_with(signing_domain)
+    const uint32_t il = L.tag[TG_I][3], dl = L.tag[TG_D][3];
+    if (il < dl) return ZKE_D_DOMAIN_MISMATCH;
+    bool bad = false;
+    for (uint32_t o = 0; o < dl; o += 64) {
+      const uint32_t l = o + lane_id();
+      if (l < dl) bad |= L.tagbuf[L.tag[TG_I][2] + il - dl + l] != L.tagbuf[L.tag[TG_D][2] + l];
+    }
+    if (__ballot(bad)) return ZKE_D_DOMAIN_MISMATCH;
+  }
+  {   // h= must name "from" (split on ':', lower-cased)
+    const uint32_t ho = L.tag[TG_H][2], hl = L.tag[TG_H][3];
+    bool found = false;
+    for (uint32_t o = 0; o < hl; o += 64) {
+      const uint32_t l = o + lane_id();
+      if (l + 4 <= hl) {
+        const uint8_t* h = L.tagbuf + ho;
+        const bool st = (l == 0) || h[l - 1] == ':';
+        const bool en = (l + 4 == hl) || h[l + 4] == ':';
+        found |= st && en && lower(h[l]) == 'f' && lower(h[l + 1]) == 'r' && lower(h[l + 2]) == 'o' && lower(h[l + 3]) == 'm';
+      }
+    }
+    if (!__ballot(found)) return ZKE_D_FROM_NOT_SIGNED;
+  }
+  if ((present & (1u << TG_Q)) && !tagval_eq(L, TG_Q, "dns/txt", 7)) return ZKE_D_BAD_QUERY_METHOD;
+  return 0;
+}
+
+// usize::from_str (optional '+', decimal digits, no overflow) on a stripped tag value
+__device__ __forceinline__ bool parse_usize_tag(const ParseLds& L, int id, uint64_t& out) {
+  const uint8_t* s = L.tagbuf + L.tag[id][2];
+  const uint32_t n = L.tag[id][3];
+  uint32_t i = 0;
+  if (n && s[0] == '+') i = 1;
+  if (i >= n) return false;
+  uint64_t v = 0;
+  for (; i < n; i++) {
+    const uint32_t c = s[i];
+    if (c < '0' || c > '9') return false;
+    const uint64_t d = c - '0';
+    if (v > (0xFFFFFFFFFFFFFFFFull - d) / 10) return false;
+    v = v * 10 + d;
+  }
+  out = v;
+  return true;
+}
+
+// ------------------------------------------------------------------ mailparse header split
+// Fills L.hdr; returns the header count or NONE with *perr set.
+__device__ __forceinline__ uint32_t split_headers(ParseLds& L, const Str& raw, uint32_t& perr) {
+  Win w; w.wpos = WNONE; w.c = 0;
+  const uint32_t len = raw.len;
+  uint32_t ix = 0, nh = 0;
+  perr = 0;
+  for (;;) {
+    if (ix >= len) break;
+    const uint32_t c0 = at(raw, w, ix);
+    if (c0 == '\n') break;
+    if (c0 == '\r') {
+      if (ix + 1 < len && at(raw, w, ix + 1) == '\n') break;
+      perr = ZKE_D_HDR_LONE_CR;
+      return NONE;
+    }
+    if (c0 == ' ') { perr = ZKE_D_HDR_LEADING_SPACE; return NONE; }
+    uint32_t key_end, vs, ve, next;
+    const uint32_t p = wfind(raw, w, ix, len, [](uint32_t c) { return c == ':' || c == '\n'; });
+    if (p >= len) {
+      key_end = len; vs = ve = len; next = len;
+    } else if (at(raw, w, p) == '\n') {
+      key_end = p; vs = ve = p; next = p + 1;
+    } else {
+      key_end = p;
+      vs = wfind(raw, w, p + 1, len, [](uint32_t c) { return c != ' '; });
+      // header end: first LF at q >= vs whose successor is not SP / HTAB (or which ends the input)
+      uint32_t q = vs;
+      for (;;) {
+        q = wfind(raw, w, q, len, [](uint32_t c) { return c == '\n'; });
+        if (q >= len) break;
+        const uint32_t nx = (q + 1 < len) ? at(raw, w, q + 1) : OOB;
+        if (nx == ' ' || nx == '\t') { q++; continue; }
+        break;
+      }
+      next = (q < len) ? q + 1 : len;
+      const uint32_t lim = (q < len) ? q : len;
+      const uint32_t lastv = wrfind(raw, w, vs, lim, [](uint32_t c) { return c != '\r' && c != '\n'; });
+      ve = (lastv == NONE) ? vs : lastv + 1;
+    }
+    if (nh >= ZKE_MAX_HEADERS) { perr = ZKE_D_U_TOO_MANY_HEADERS; return NONE; }
+    if (lane_id() == 0) { L.hdr[4 * nh] = ix; L.hdr[4 * nh + 1] = key_end; L.hdr[4 * nh + 2] = vs; L.hdr[4 * nh + 3] = ve; }
+    nh++;
+    ix = next;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  return nh;
+}
+
+// cfdkim get_body: everything after the first CRLFCRLF (empty when there is none)
+__device__ __forceinline__ uint32_t find_body(const Str& raw) {
+  const uint32_t len = raw.len;
+  for (uint32_t base = 0; base + 4 <= len; base += 61) {
+    const uint32_t c = ldb(raw, base + lane_id());
+    const uint64_t r = __ballot(c == '\r'), n = __ballot(c == '\n');
+    uint64_t m = r & (n >> 1) & (r >> 2) & (n >> 3) & bits_below(61);
+    if (m) return base + (uint32_t)__builtin_ctzll(m) + 4;
+  }
+  return len;
+}
+
+// ------------------------------------------------------------------ PKCS#1 RSAPublicKey DER
+__device__ __forceinline__ uint32_t der_len(const Str& k, Win& w, uint32_t p, uint32_t avail, uint32_t& out) {
+  if (avail < 1) return 0;
+  const uint32_t b0 = at(k, w, p);
+  if (b0 < 0x80) { out = b0; return 1; }
+  const uint32_t nb = b0 & 0x7f;
+  if (nb == 0 || nb > 4 || nb + 1 > avail) return 0;
+  uint32_t v = 0;
+  for (uint32_t i = 0; i < nb; i++) v = (v << 8) | at(k, w, p + 1 + i);
+  if (at(k, w, p + 1) == 0) return 0;
+  if (nb == 1 && v < 0x80) return 0;
+  if (nb == 4 && (v >> 31)) return 0;
+  out = v;
+  return nb + 1;
+}
+// INTEGER at p: value span [vp, vp+vl) with one sign octet stripped; returns bytes used or 0
+__device__ __forceinline__ uint32_t der_uint(const Str& k, Win& w, uint32_t p, uint32_t avail, uint32_t& vp, uint32_t& vl) {
+  if (avail < 2 || at(k, w, p) != 0x02) return 0;
+  uint32_t l, c = der_len(k, w, p + 1, avail - 1, l);
+  if (!c || l == 0 || (uint64_t)1 + c + l > avail) return 0;
+  uint32_t s = p + 1 + c;
+  const uint32_t v0 = at(k, w, s);
+  if (v0 & 0x80) return 0;
+  if (l > 1 && v0 == 0 && !(at(k, w, s + 1) & 0x80)) return 0;
+  vp = s; vl = l;
+  if (l > 1 && v0 == 0) { vp = s + 1; vl = l - 1; }
+  return 1 + c + l;
+}
+// returns 0 or ZKE_D_KEY_*; fills the RSA job's modulus / exponent
+__device__ __forceinline__ uint32_t decode_rsa_key(const Str& k, RsaJob* J, uint32_t& bits_out, uint32_t& even) {
+  Win w; w.wpos = WNONE; w.c = 0;
+  const uint32_t len = k.len;
+  if (len < 2 || at(k, w, 0) != 0x30) return ZKE_D_KEY_DER;
+  uint32_t sl, c = der_len(k, w, 1, len - 1, sl);
+  if (!c || (uint64_t)1 + c + sl != len) return ZKE_D_KEY_DER;
+  uint32_t p = 1 + c, avail = sl, np, nl, ep, el;
+  uint32_t used = der_uint(k, w, p, avail, np, nl);
+  if (!used) return ZKE_D_KEY_DER;
+  p += used; avail -= used;
+  used = der_uint(k, w, p, avail, ep, el);
+  if (!used || used != avail) return ZKE_D_KEY_DER;
+  const uint32_t n0 = at(k, w, np);
+  uint32_t bits = 0;
+  if (!(nl == 1 && n0 == 0)) bits = nl * 8 - (uint32_t)(__builtin_clz(n0) - 24);
+  if (bits > 4096) return ZKE_D_KEY_RANGE;
+  if (el > 8) return ZKE_D_KEY_RANGE;
+  uint64_t e = 0;
+  for (uint32_t i = 0; i < el; i++) e = (e << 8) | at(k, w, ep + i);
+  if (e < 2 || e > ((1ull << 33) - 1)) return ZKE_D_KEY_RANGE;
+  // modulus, big-endian, right-aligned in the 512-byte field (zero fill in front)
+  for (uint32_t o = lane_id(); o < 512; o += 64) {
+    uint8_t b = 0;
+    if (o >= 512 - nl) b = (uint8_t)ldb(k, np + (o - (512 - nl)));
+    J->mod[o] = b;
+  }
+  even = !(at(k, w, np + nl - 1) & 1) && bits != 0;
+  if (lane_id() == 0) { J->e = e; J->k = nl; J->bits = bits; }
+  bits_out = bits;
+  return 0;
+}
+
+// base64 STANDARD decode of tagbuf[off, off+n) into J->sig (right-aligned).  false = not canonical base64.
+__device__ __forceinline__ uint32_t b64v(uint32_t c) {
+  if (c >= 'A' && c <= 'Z') return c - 'A';
+  if (c >= 'a' && c <= 'z') return c - 'a' + 26;
+  if (c >= '0' && c <= '9') return c - '0' + 52;
+  if (c == '+') return 62;
+  if (c == '/') return 63;
+  return 64;
+}
+__device__ __forceinline__ bool decode_sig(const ParseLds& L, uint32_t off, uint32_t n, RsaJob* J, uint32_t& sig_len) {
+  sig_len = 0;
+  const uint8_t* s = L.tagbuf + off;
+  uint32_t pad = 0, total = 0;
+  const bool shape_ok = (n % 4) == 0;
+  if (shape_ok && n) {
+    pad = (s[n - 1] == '=') ? ((s[n - 2] == '=') ? 2u : 1u) : 0u;
+    total = 3 * (n / 4) - pad;
+  }
+  {   // zero the part of the field the decoded bytes will not cover
+    const uint32_t zend = (shape_ok && total <= 512) ? 512 - total : 512;
+    for (uint32_t o = lane_id(); o < zend; o += 64) J->sig[o] = 0;
+  }
+  if (!shape_ok) return false;
+  if (n == 0) return true;
+  bool bad = false;
+  for (uint32_t q0 = 0; q0 < n / 4; q0 += 64) {
+    const uint32_t q = q0 + lane_id();
+    if (q < n / 4) {
+      const bool last = (q + 1 == n / 4);
+      const uint32_t a = b64v(s[4 * q]), b = b64v(s[4 * q + 1]);
+      uint32_t c = b64v(s[4 * q + 2]), d = b64v(s[4 * q + 3]);
+      uint32_t nb = 3;
+      if (last && pad == 2) { c = 0; d = 0; nb = 1; if (b & 15) bad = true; }
+      else if (last && pad == 1) { d = 0; nb = 2; if (c < 64 && (c & 3)) bad = true; }
+      if (a > 63 || b > 63 || c > 63 || d > 63) bad = true;
+      const uint32_t v = (a << 18) | (b << 12) | (c << 6) | d;
+      if (total <= 512) {
+        const uint32_t dst = 512 - total + 3 * q;
+        J->sig[dst] = (uint8_t)(v >> 16);
+        if (nb > 1) J->sig[dst + 1] = (uint8_t)(v >> 8);
+        if (nb > 2) J->sig[dst + 2] = (uint8_t)v;
+      }
+    }
+  }
+  sig_len = total;
+  return __ballot(bad) == 0;
+}
+
+// Does v[p, p+n) equal v[a, a+n)?
+__device__ __forceinline__ bool same_bytes(const Str& v, uint32_t p, uint32_t a, uint32_t n) {
+  for (uint32_t o = 0; o < n; o += 64) {
+    const uint32_t l = o + lane_id();
+    bool bad = l < n && ldb(v, p + l) != ldb(v, a + l);
+    if (__ballot(bad)) return false;
+  }
+  return true;
+}
+
+// ------------------------------------------------------------------ the parse kernel
+// mode 0: verify_email_with_key scan (round r picks the r-th same-domain candidate)
+// mode 1: canonicalize_signed_email (first DKIM-Signature header, no domain filter; core/src/circuits.rs:34-35)
+struct ParseArgs { BatchDev b; uint32_t round; uint32_t mode; };
+
+__device__ const uint8_t DKIM_NAME[14] = {'D', 'K', 'I', 'M', '-', 'S', 'i', 'g', 'n', 'a', 't', 'u', 'r', 'e'};
+
+__global__ __launch_bounds__(64) void parse_kernel(ParseArgs A) {
+  __shared__ ParseLds L;
+  const BatchDev& B = A.b;
+  const uint32_t i = blockIdx.x;
+  if (i >= B.n) return;
+  const int lane = lane_id();
+  EmailMeta* M = B.meta + i;
+  zke_result* R = B.results + i;
+  RsaJob* J = B.rsa + i;
+  const uint32_t round = A.round;
+  if (round > 0 && M->state != ST_PENDING) return;
+
+  const uint64_t r0 = B.raw_off[i], r1 = B.raw_off[i + 1];
+  const Str raw = mkstr(B.raw + r0, (uint32_t)(r1 - r0));
+  const Str dom = mkstr(B.dom + B.dom_off[i], (uint32_t)(B.dom_off[i + 1] - B.dom_off[i]));
+  const Str key = mkstr(B.key + B.key_off[i], (uint32_t)(B.key_off[i + 1] - B.key_off[i]));
+  uint8_t* regA = B.scratch + B.scratch_off[i];
+  const uint32_t capA = raw.len + PRE_SLACK;
+
+  auto sha_job = [&](uint32_t kind, const void* src, uint32_t len, void* dst) {
+    if (lane == 0 && A.mode == 0) {
+      ShaJob j; j.src = (uint64_t)src; j.dst = (uint64_t)dst; j.len = len; j.pad = 0;
+      B.sha[(size_t)kind * B.n_pad + i] = j;
+    }
+  };
+  auto finish = [&](uint32_t status, uint32_t detail) {
+    if (lane == 0) { M->state = ST_FINAL; M->status = status; M->detail = detail; }
+  };
+
+  if (A.mode == 1) {
+    // canonicalize_signed_email runs only for e-mails whose verify_email succeeded (circuits.rs:32-35)
+    for (uint32_t o = lane; o < sizeof(EmailMeta) / 4; o += 64) ((uint32_t*)M)[o] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    if (R->status != ZKE_OK) { finish(R->status, R->detail); return; }
+    const EmailMeta* V = B.meta_verify + i;
+    if (V->first_sig_hdr == V->cand_hdr) {        // same signature: nothing to recompute
+      if (lane == 0) {
+        M->state = ST_CAND; M->reuse = 1; M->flags = V->flags; M->preimage_len = V->preimage_len;
+        M->body_off = V->body_off; M->body_len = V->body_len; M->canon_full_len = V->canon_full_len;
+        M->hashed_len = V->hashed_len; M->body_src_is_raw = V->body_src_is_raw;
+        M->len_tag_lo = V->len_tag_lo; M->len_tag_hi = V->len_tag_hi;
+      }
+      return;
+    }
+  } else if (round == 0) {
+    // result record and meta start from zero
+    for (uint32_t o = lane; o < sizeof(zke_result) / 4; o += 64) ((uint32_t*)R)[o] = 0;
+    for (uint32_t o = lane; o < sizeof(EmailMeta) / 4; o += 64) ((uint32_t*)M)[o] = 0;
+    for (uint32_t k = 0; k < 4; k++) sha_job(k, nullptr, 0, nullptr);
+    if (lane == 0) { J->flags = 0; J->bits = 0; J->k = 0; J->sig_len = 0; J->e = 0; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    if (lane == 0) R->regex_part = 0xFFFFFFFFu;
+    if (r1 - r0 >= (1ull << 31)) { finish(ZKE_UNSUPPORTED, ZKE_D_U_EMAIL_TOO_LARGE); return; }
+  } else {
+    for (uint32_t k = 0; k < 4; k++) sha_job(k, nullptr, 0, nullptr);
+    if (lane == 0) J->flags = 0;
+  }
+
+  // ---- mailparse::parse_mail (core/src/email.rs:26)
+  uint32_t perr;
+  const uint32_t nh = split_headers(L, raw, perr);
+  if (nh == NONE) {
+    finish(perr == ZKE_D_U_TOO_MANY_HEADERS ? ZKE_UNSUPPORTED : ZKE_PARSE_FAIL, perr);
+    return;
+  }
+  const uint32_t body_off = find_body(raw);
+  if (lane == 0) {
+    if (A.mode == 0) { R->n_headers = nh; R->body_offset = body_off; }
+    M->n_headers = nh; M->body_off = body_off; M->body_len = raw.len - body_off;
+  }
+
+  // ---- DkimPublicKey::try_from_bytes (core/src/email.rs:28-29)
+  if (round == 0 && A.mode == 0) {
+    const uint32_t kt = B.key_type[i];
+    if (kt == ZKE_KEY_ED25519) {
+      if (key.len != 32) finish(ZKE_KEY_DECODE_FAIL, ZKE_D_KEY_DER); else finish(ZKE_UNSUPPORTED, ZKE_D_U_ALGO_ED25519);
+      return;
+    }
+    if (kt != ZKE_KEY_RSA) { finish(ZKE_KEY_DECODE_FAIL, ZKE_D_KEY_TYPE); return; }
+    uint32_t bits = 0, even = 0;
+    const uint32_t kr = decode_rsa_key(key, J, bits, even);
+    if (kr) { finish(ZKE_KEY_DECODE_FAIL, kr); return; }
+    if (lane == 0) { R->rsa_bits = bits; M->key_ok = 1; M->even_modulus = even; }
+    // the two output witnesses (core/src/circuits.rs:16-17)
+    sha_job(2, dom.base, dom.len, R->from_domain_hash);
+    sha_job(3, key.base, key.len, R->public_key_hash);
+  }
+
+  // ---- scan the DKIM-Signature headers in file order
+  uint32_t sig_ix = 0, cand_count = 0, last_touched = 0, unsupported = 0;
+  uint32_t err_all = 0;        // last non-candidate error anywhere
+  uint32_t err_after = 0;      // last non-candidate error after this round's candidate
+  bool have_cand = false;
+  uint32_t first_sig_hdr = NONE;
+  for (uint32_t hx = 0; hx < nh; hx++) {
+    const uint32_t ks = L.hdr[4 * hx], ke = L.hdr[4 * hx + 1], vs = L.hdr[4 * hx + 2], ve = L.hdr[4 * hx + 3];
+    if (!span_ieq(raw, ks, ke - ks, DKIM_NAME, 14)) continue;
+    const uint32_t this_ix = sig_ix++;
+    if (first_sig_hdr == NONE) first_sig_hdr = hx;
+    if (A.mode == 1 && hx != first_sig_hdr) break;
+    const Str v = mkstr(raw.base + vs, ve - vs);
+    auto note_err = [&](uint32_t e) { err_all = e; if (have_cand) err_after = e; last_touched = this_ix; };
+    // from_utf8_lossy would rewrite invalid UTF-8: any byte >= 0x80 is reported, never guessed
+    {
+      Win w; w.wpos = WNONE; w.c = 0;
+      if (wfind(v, w, 0, v.len, [](uint32_t c) { return c >= 0x80 && c != OOB; }) < v.len) {
+        unsupported = ZKE_D_U_SIG_NON_ASCII; last_touched = this_ix;
+        if (A.mode == 1) { finish(ZKE_UNSUPPORTED, unsupported); return; }
+        continue;
+      }
+    }
+    uint32_t present;
+    const uint32_t verr = validate_sig(L, v, present);
+    if (verr == ZKE_D_U_TOO_MANY_TAGS || verr == ZKE_D_U_SIG_TOO_LONG) {
+      unsupported = verr; last_touched = this_ix;
+      if (A.mode == 1) { finish(ZKE_UNSUPPORTED, verr); return; }
+      continue;
+    }
+    if (verr) {
+      if (A.mode == 1) { finish(ZKE_CANON_FAIL, verr); return; }
+      note_err(verr);
+      continue;
+    }
+    if (A.mode == 0) {
+      // signing_domain.to_lowercase() == from_domain.to_lowercase()
+      bool same = L.tag[TG_D][3] == dom.len;
+      if (same) {
+        bool bad = false;
+        for (uint32_t o = 0; o < dom.len; o += 64) {
+          const uint32_t l = o + lane;
+          if (l < dom.len) bad |= lower(L.tagbuf[L.tag[TG_D][2] + l]) != lower(ldb(dom, l));
+        }
+        same = __ballot(bad) == 0;
+      }
+      if (!same) continue;
+    }
+    last_touched = this_ix;
+    // c=, a=, l=  (parser::parse_canonicalization, parse_hash_algo, compute_body_hash's length parse)
+    uint32_t flags = 0;
+    if (present & (1u << TG_C)) {
+      if (tagval_eq(L, TG_C, "simple/simple", 13) || tagval_eq(L, TG_C, "simple", 6)) flags = 0;
+      else if (tagval_eq(L, TG_C, "relaxed/simple", 14) || tagval_eq(L, TG_C, "relaxed", 7)) flags = ZKE_F_HDR_RELAXED;
+      else if (tagval_eq(L, TG_C, "simple/relaxed", 14)) flags = ZKE_F_BODY_RELAXED;
+      else if (tagval_eq(L, TG_C, "relaxed/relaxed", 15)) flags = ZKE_F_HDR_RELAXED | ZKE_F_BODY_RELAXED;
+      else {
+        if (A.mode == 1) { finish(ZKE_CANON_FAIL, ZKE_D_BAD_CANON); return; }
+        note_err(ZKE_D_BAD_CANON); continue;
+      }
+    }
+    if (A.mode == 0) {
+      if (tagval_eq(L, TG_A, "rsa-sha256", 10)) {}
+      else if (tagval_eq(L, TG_A, "rsa-sha1", 8)) { unsupported = ZKE_D_U_ALGO_SHA1; continue; }
+      else if (tagval_eq(L, TG_A, "ed25519-sha256", 14)) { unsupported = ZKE_D_U_ALGO_ED25519; continue; }
+      else { note_err(ZKE_D_BAD_ALGO); continue; }
+    }
+    uint64_t len_tag = 0;
+    if (present & (1u << TG_L)) {
+      if (!parse_usize_tag(L, TG_L, len_tag)) {
+        if (A.mode == 1) { finish(ZKE_CANON_FAIL, ZKE_D_BAD_LENGTH); return; }
+        note_err(ZKE_D_BAD_LENGTH); continue;
+      }
+      flags |= ZKE_F_HAS_LENGTH;
+    }
+    // this signature reaches the hash stage
+    const uint32_t my_cand = cand_count++;
+    if (my_cand != round) continue;
+    have_cand = true; err_after = 0;
+
+    // ---- the b= value: decode, and locate its raw span for removal from the preimage
+    const uint32_t b_rs = L.tag[TG_B][0], b_re = L.tag[TG_B][1];
+    if (A.mode == 0) {
+      uint32_t sig_len = 0;
+      const bool b64ok = decode_sig(L, L.tag[TG_B][2], L.tag[TG_B][3], J, sig_len);
+      if (lane == 0) {
+        M->sig_b64_ok = b64ok ? 1u : 0u;
+        J->sig_len = sig_len;
+        const uint32_t bl = L.tag[TG_BH][3];
+        M->bh_len = bl;
+      }
+      for (uint32_t o = lane; o < 48; o += 64) M->bh[o] = o < L.tag[TG_BH][3] ? L.tagbuf[L.tag[TG_BH][2] + o] : 0;
+    }
+    // String::replace removes every occurrence of the raw b= value; the device removes the tag's own span
+    // and reports any second occurrence instead of guessing
+    const uint32_t bl = b_re - b_rs;
+    if (bl) {
+      Win w; w.wpos = WNONE; w.c = 0;
+      const uint32_t fl = bl < 8 ? bl : 8;
+      bool repeated = false;
+      for (uint32_t base = 0; base + bl <= v.len && !repeated; base += 64) {
+        const uint32_t p = base + lane;
+        bool cand = p + bl <= v.len && p != b_rs;
+        for (uint32_t t = 0; t < fl && cand; t++) cand = ldb(v, p + t) == ldb(v, b_rs + t);
+        uint64_t m = __ballot(cand);
+        while (m && !repeated) {
+          const uint32_t q = base + (uint32_t)__builtin_ctzll(m);
+          m &= m - 1;
+          if (same_bytes(v, q, b_rs, bl)) repeated = true;
+        }
+      }
+      if (repeated) {
+        unsupported = ZKE_D_U_SIG_B_REPEATED;
+        if (A.mode == 1) { finish(ZKE_UNSUPPORTED, unsupported); return; }
+        have_cand = false; cand_count--;      // not hashable on the device: treated like an unsupported signature
+        continue;
+      }
+    }
+    // ---- header-hash preimage (cfdkim hash::compute_headers_hash)
+    Out out{regA, 0, capA, false};
+    const bool hrel = (flags & ZKE_F_HDR_RELAXED) != 0;
+    {
+      const uint8_t* h = L.tagbuf + L.tag[TG_H][2];
+      const uint32_t hl = L.tag[TG_H][3];
+      uint32_t st = 0;
+      for (uint32_t e = 0; e <= hl; e++) {
+        if (e != hl && h[e] != ':') continue;
+        // bottom-up cursor per (lower-cased) name: the latest earlier entry of h= with the same name decides
+        uint32_t start = nh;
+        {
+          uint32_t st2 = 0;
+          // replay the selection for earlier identical names (names per signature are few)
+          uint32_t cur = nh;
+          for (uint32_t e2 = 0; e2 < st; e2++) {
+            if (h[e2] != ':' ) continue;
+            // entry [st2, e2)
+            bool same = (e2 - st2) == (e - st);
+            if (same) {
+              bool bad = false;
+              for (uint32_t o = lane; o < e - st; o += 64) bad |= lower(h[st2 + o]) != lower(h[st + o]);
+              same = __ballot(bad) == 0;
+            }
+            if (same) {
+              uint32_t found = NONE;
+              for (uint32_t x = cur; x-- > 0;) {
+                const uint32_t ks2 = L.hdr[4 * x], ke2 = L.hdr[4 * x + 1];
+                if (span_ieq(raw, ks2, ke2 - ks2, h + st2, e2 - st2)) { found = x; break; }
+              }
+              cur = (found == NONE) ? 0 : found;
+            }
+            st2 = e2 + 1;
+          }
+          start = cur;
+        }
+        uint32_t found = NONE;
+        for (uint32_t x = start; x-- > 0;) {
+          const uint32_t ks2 = L.hdr[4 * x], ke2 = L.hdr[4 * x + 1];
+          if (span_ieq(raw, ks2, ke2 - ks2, h + st, e - st)) { found = x; break; }
+        }
+        if (found != NONE) {
+          const uint32_t* sp = L.hdr + 4 * found;
+          emit_header(out, mkstr(raw.base + sp[0], sp[1] - sp[0]), mkstr(raw.base + sp[2], sp[3] - sp[2]), hrel, true);
+        }
+        st = e + 1;
+      }
+    }
+    {
+      Str sv = v;
+      if (bl) { sv.len = v.len - bl; sv.cut = b_rs; sv.skip = bl; }
+      emit_header(out, mkstr(DKIM_NAME, 14), sv, hrel, false);
+    }
+    if (out.overflow) {
+      unsupported = ZKE_D_U_PREIMAGE_OVERFLOW;
+      if (A.mode == 1) { finish(ZKE_UNSUPPORTED, unsupported); return; }
+      have_cand = false; cand_count--;
+      continue;
+    }
+    if (lane == 0) {
+      M->cand_sig_index = this_ix; M->cand_hdr = hx; M->flags = flags;
+      M->len_tag_lo = (uint32_t)len_tag; M->len_tag_hi = (uint32_t)(len_tag >> 32);
+      M->preimage_len = out.o;
+      if (A.mode == 0) { R->flags = flags; R->canon_header_len = out.o; R->sig_index = this_ix; }
+    }
+    if (A.mode == 0) sha_job(1, regA, out.o, R->header_hash);
+    if (A.mode == 1) break;
+  }
+  if (A.mode == 1) {
+    if (!have_cand) { finish(ZKE_CANON_FAIL, first_sig_hdr == NONE ? ZKE_D_NO_SIGNATURE : ZKE_D_SIG_SYNTAX); return; }
+    if (lane == 0) { M->state = ST_CAND; M->first_sig_hdr = first_sig_hdr; }
+    return;
+  }
+  if (lane == 0) {
+    M->n_sigs = sig_ix; M->cand_total = cand_count; M->unsupported = unsupported; M->last_touched_sig = last_touched;
+    M->post_err = err_after; M->pre_err = err_all; M->first_sig_hdr = first_sig_hdr;
+  }
+  if (!have_cand) {
+    // nothing (more) to hash: neutral / last error / unsupported (core/src/circuits.rs:13 panics either way)
+    if (lane == 0) R->sig_index = last_touched;
+    if (unsupported) finish(ZKE_UNSUPPORTED, unsupported);
+    else finish(ZKE_DKIM_NOT_PASS, err_all ? err_all : (round == 0 ? ZKE_D_NEUTRAL : M->cand_err));
+    return;
+  }
+  if (lane == 0) {
+    M->state = ST_CAND;
+    uint32_t f = RSA_F_ACTIVE;
+    J->flags = f;
+  }
+}
+
+// CSR (blob, off[n+1]) -> ShaJob list with digests packed 32 B apart (building-block entry point)
 __global__ void sha_jobs_from_csr_kernel(const uint8_t* blob, const uint64_t* off, uint32_t n, uint8_t* digests, ShaJob* jobs) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -14,4 +849,5 @@ __global__ void sha_jobs_from_csr_kernel(const uint8_t* blob, const uint64_t* of
   j.pad = 0;
   jobs[i] = j;
 }
-}
+
+}  // namespace zke

@@ -1,7 +1,418 @@
+// pipeline.hip.h — host orchestration of one batch: workspace sizing, the kernel sequence of
+// verify_email / verify_email_with_regex (core/src/circuits.rs:9-68), DFA registration.
+// Included by engine.hip (single translation unit).
 #pragma once
-extern "C" {
-int zke_dfa_register(zke_engine* e, const uint8_t*, size_t, const uint8_t*, size_t, uint32_t*) { return fail(e, ZKE_E_DEVICE, "not built yet"); }
-int zke_verify_batch(zke_engine* e, const zke_batch*, zke_result*, zke_debug_out*) { return fail(e, ZKE_E_DEVICE, "not built yet"); }
-int zke_verify_batch_device(zke_engine* e, const zke_batch*, uint64_t, uint64_t, uint64_t, zke_result*, void*) { return fail(e, ZKE_E_DEVICE, "not built yet"); }
-int zke_verify_email(zke_engine* e, const uint8_t*, size_t, const char*, size_t, const uint8_t*, size_t, uint32_t, zke_result*) { return fail(e, ZKE_E_DEVICE, "not built yet"); }
+
+namespace {
+
+constexpr uint32_t SCR_PER_EMAIL = PRE_SLACK + 64;      // fixed part of an e-mail's scratch slot
+constexpr uint32_t CLEAN_PER_EMAIL = 32;
+
+// scratch_off[i] = align16(2 * (raw_off[i] - raw_off[0])) + i * SCR_PER_EMAIL   (region A then region B, see parse.hip.h)
+// clean_off[i]   = (raw_off[i] - raw_off[0]) + i * CLEAN_PER_EMAIL
+__global__ void offsets_kernel(const uint64_t* raw_off, uint32_t n, uint64_t* scratch_off, uint64_t* clean_off) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n) return;
+  const uint64_t rel = raw_off[i] - raw_off[0];
+  scratch_off[i] = ((2 * rel + 15) & ~15ull) + (uint64_t)i * SCR_PER_EMAIL;
+  clean_off[i] = rel + (uint64_t)i * CLEAN_PER_EMAIL;
 }
+
+inline uint64_t host_scratch_off(const uint64_t* raw_off, uint32_t i) {
+  const uint64_t rel = raw_off[i] - raw_off[0];
+  return ((2 * rel + 15) & ~15ull) + (uint64_t)i * SCR_PER_EMAIL;
+}
+
+struct StageTimer {
+  zke_engine* e; hipStream_t s; int k = 0; bool on;
+  StageTimer(zke_engine* e_, hipStream_t s_) : e(e_), s(s_), on(e_->timing) {}
+  void mark() { if (on && k < 16) (void)hipEventRecord(e->ev[k++], s); }
+};
+
+// The device pipeline.  Every pointer in `in` / out_dev is device memory.
+int run_device_pipeline(zke_engine* e, const zke_batch* in, uint64_t raw_total, zke_result* out_dev, hipStream_t s,
+                        bool want_em) {
+  const uint32_t n = in->n;
+  if (n == 0) return 0;
+  const uint32_t n_pad = (n + 63) & ~63u;
+  const uint32_t P = in->with_regex ? in->n_header_parts + in->n_body_parts : 0;
+  int r = 0;
+  const size_t scratch_bytes = 2 * (size_t)raw_total + (size_t)(n + 1) * SCR_PER_EMAIL + 256;
+  if ((r = e->meta.ensure((size_t)n * sizeof(EmailMeta))) || (r = e->rsa_jobs.ensure((size_t)n * sizeof(RsaJob))) ||
+      (r = e->sha_jobs.ensure((size_t)4 * n_pad * sizeof(ShaJob))) || (r = e->rsa_ok.ensure((size_t)n * 4)) ||
+      (r = e->scratch_off.ensure((size_t)(n + 1) * 16)) || (r = e->scratch.ensure(scratch_bytes)))
+    return fail(e, r, "workspace allocation");
+  if (want_em && (r = e->em_dbg.ensure((size_t)n * 512))) return fail(e, r, "workspace allocation");
+  if (in->with_regex) {
+    if ((r = e->meta2.ensure((size_t)n * sizeof(EmailMeta))) || (r = e->scratch2.ensure(scratch_bytes)) ||
+        (r = e->clean.ensure((size_t)raw_total + (size_t)(n + 1) * CLEAN_PER_EMAIL + 256)) ||
+        (r = e->parts.ensure((size_t)n * std::max<uint32_t>(P, 1) * sizeof(PartRes))))
+      return fail(e, r, "workspace allocation");
+  }
+  uint64_t* scratch_off = e->scratch_off.as<uint64_t>();
+  uint64_t* clean_off = scratch_off + (n + 1);
+
+  StageTimer tm(e, s);
+  tm.mark();
+  hipLaunchKernelGGL(offsets_kernel, dim3((n + 1 + 255) / 256), dim3(256), 0, s, in->raw_off, n, scratch_off, clean_off);
+  // jobs of the padding lanes of the last wave of each kind must read as inactive
+  HIPCHK(e, hipMemsetAsync(e->sha_jobs.p, 0, (size_t)4 * n_pad * sizeof(ShaJob), s));
+
+  BatchDev B{};
+  B.n = n;
+  B.raw = in->raw_blob; B.raw_off = in->raw_off;
+  B.dom = in->domain_blob; B.dom_off = in->domain_off;
+  B.key = in->key_blob; B.key_off = in->key_off;
+  B.key_type = in->key_type; B.ext_null = in->ext_null;
+  B.results = out_dev;
+  B.meta = e->meta.as<EmailMeta>();
+  B.rsa = e->rsa_jobs.as<RsaJob>();
+  B.sha = e->sha_jobs.as<ShaJob>();
+  B.n_pad = n_pad;
+  B.scratch = e->scratch.as<uint8_t>();
+  B.scratch_off = scratch_off;
+  B.meta_verify = nullptr;
+
+  const uint32_t rounds = std::max<uint32_t>(1, e->max_sig_rounds);
+  for (uint32_t round = 0; round < rounds; round++) {
+    ParseArgs pa{B, round, 0};
+    hipLaunchKernelGGL(parse_kernel, dim3(n), dim3(64), 0, s, pa);
+    if (round == 0) tm.mark();
+    CanonArgs ca{B, 0};
+    hipLaunchKernelGGL(canon_body_kernel, dim3(n), dim3(64), 0, s, ca);
+    if (round == 0) tm.mark();
+    if ((r = launch_sha<SHA_TILE>(e, B.sha, 4 * n_pad, s))) return r;
+    if (round == 0) tm.mark();
+    if ((r = launch_rsa(e, B.rsa, n, reinterpret_cast<const uint8_t*>(out_dev) + offsetof(zke_result, header_hash),
+                        sizeof(zke_result), e->rsa_ok.as<uint32_t>(), want_em ? e->em_dbg.as<uint8_t>() : nullptr, s, true)))
+      return r;
+    if (round == 0) tm.mark();
+    FinArgs fa{B, e->rsa_ok.as<uint32_t>(), round, rounds};
+    hipLaunchKernelGGL(finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, s, fa);
+    if (round == 0) tm.mark();
+  }
+  HIPCHK(e, hipGetLastError());
+
+  if (in->with_regex) {
+    // canonicalize_signed_email (circuits.rs:34-35): first DKIM-Signature header, own scratch unless it is the verified one
+    BatchDev B2 = B;
+    B2.meta = e->meta2.as<EmailMeta>();
+    B2.scratch = e->scratch2.as<uint8_t>();
+    B2.meta_verify = B.meta;
+    ParseArgs pa{B2, 0, 1};
+    hipLaunchKernelGGL(parse_kernel, dim3(n), dim3(64), 0, s, pa);
+    CanonArgs ca{B2, 1};
+    hipLaunchKernelGGL(canon_body_kernel, dim3(n), dim3(64), 0, s, ca);
+    QpArgs qa{B2, B.meta, e->clean.as<uint8_t>(), clean_off, B.scratch, B.scratch_off};
+    if (in->n_body_parts) hipLaunchKernelGGL(qp_kernel, dim3(n), dim3(64), 0, s, qa);
+    tm.mark();
+    for (uint32_t p = 0; p < P; p++) {
+      const bool is_body = p >= in->n_header_parts;
+      // part ids are host-visible only in host mode; zke_verify_batch_device receives them as host arrays too
+      const uint32_t id = is_body ? e->host_body_ids[p - in->n_header_parts] : e->host_hdr_ids[p];
+      const RegisteredDfa* rd = id < e->dfas.size() ? e->dfas[id] : nullptr;
+      DfaArgs da{};
+      da.b = B2; da.re = (rd && rd->valid) ? rd->dev.as<RegexDev>() : nullptr;
+      da.part = p; da.P = P; da.is_body = is_body ? 1 : 0;
+      da.scratch_v = B.scratch; da.scratch_v_off = B.scratch_off;
+      da.clean = e->clean.as<uint8_t>(); da.clean_off = clean_off;
+      da.cap_off = in->cap_off; da.cap_str_off = in->cap_str_off; da.cap_blob = in->cap_blob;
+      da.out = e->parts.as<PartRes>();
+      size_t lds = 1024;
+      da.lds_tables = 0;
+      if (rd && rd->valid && rd->lds_bytes + 1024 <= 150 * 1024) { da.lds_tables = 1; lds = rd->lds_bytes + 1024; }
+      if (lds > e->dfa_lds_attr) {
+        HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&dfa_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        e->dfa_lds_attr = lds;
+      }
+      hipLaunchKernelGGL(dfa_kernel, dim3((n + 255) / 256), dim3(256), lds, s, da);
+    }
+    RegexFinArgs rf{B2, e->parts.as<PartRes>(), in->n_header_parts, in->n_body_parts};
+    hipLaunchKernelGGL(regex_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, s, rf);
+    tm.mark();
+    HIPCHK(e, hipGetLastError());
+  }
+  tm.mark();
+  e->timed_marks = tm.k;
+  e->timed_regex = in->with_regex != 0;
+  return 0;
+}
+
+void collect_timings(zke_engine* e) {
+  if (!e->timing || e->timed_marks < 7) return;
+  auto dt = [&](int a, int b) { float ms = 0; (void)hipEventElapsedTime(&ms, e->ev[a], e->ev[b]); return ms * 1000.f; };
+  zke_timings& t = e->last;
+  t.parse_us = dt(0, 1); t.canon_body_us = dt(1, 2); t.sha_us = dt(2, 3); t.rsa_us = dt(3, 4); t.finalize_us = dt(4, 5);
+  if (e->timed_regex && e->timed_marks >= 9) { t.qp_us = dt(5, 6); t.dfa_us = dt(6, 7); }
+  else { t.qp_us = 0; t.dfa_us = 0; }
+  t.total_us = dt(0, e->timed_marks - 1);
+}
+
+// ---- regex-automata 0.4.9 dense DFA, little-endian wire format ----
+uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+struct HostDfa {
+  DfaDev d{};
+  std::vector<uint32_t> table;
+};
+
+// dense::DFA::from_bytes restated: structure, sizes and the id validity checks.  false = would not deserialise.
+bool parse_dfa_blob(const uint8_t* b, size_t n, HostDfa& h) {
+  static const char LABEL[] = "rust-regex-automata-dfa-dense";
+  DfaDev& d = h.d;
+  size_t p = 0;
+  while (p < n && p < 7 && b[p] == 0) p++;
+  auto need = [&](size_t k) { return n - p >= k; };
+  if (!need(32) || memcmp(b + p, LABEL, 29) || b[p + 29] != 0) return false;
+  p += 32;
+  if (!need(4) || rd32(b + p) != 0xFEFF) return false; p += 4;
+  if (!need(4) || rd32(b + p) != 2) return false; p += 4;
+  if (!need(4)) return false; p += 4;
+  if (!need(12)) return false;
+  d.has_empty = rd32(b + p); d.is_utf8 = rd32(b + p + 4); d.always_anchored = rd32(b + p + 8);
+  p += 12;
+  if (!need(8 + 256)) return false;
+  d.state_len = rd32(b + p); d.stride2 = rd32(b + p + 4); p += 8;
+  memcpy(d.classes, b + p, 256); p += 256;
+  if (d.stride2 < 1 || d.stride2 > 9) return false;
+  d.alphabet_len = (uint32_t)d.classes[255] + 2;
+  if (d.alphabet_len > (1u << d.stride2)) return false;
+  if (d.state_len > (1u << 26)) return false;
+  const size_t tl = (size_t)d.state_len << d.stride2;
+  if (!need(tl * 4)) return false;
+  d.table_len = (uint32_t)tl;
+  h.table.resize(tl);
+  for (size_t i = 0; i < tl; i++) h.table[i] = rd32(b + p + 4 * i);
+  p += tl * 4;
+  const uint32_t stride = 1u << d.stride2;
+  for (size_t s = 0; s < d.state_len; s++)
+    for (uint32_t c = 0; c < d.alphabet_len; c++) {
+      const uint32_t id = h.table[(s << d.stride2) + c];
+      if (id >= tl || (id & (stride - 1))) return false;
+    }
+  if (!need(4 + 256 + 16)) return false;
+  d.start_kind = rd32(b + p); p += 4;
+  if (d.start_kind > 2) return false;
+  memcpy(d.start_map, b + p, 256); p += 256;
+  for (int i = 0; i < 256; i++) if (d.start_map[i] >= 6) return false;
+  if (rd32(b + p) != 6) return false; p += 4;
+  const uint32_t spl = rd32(b + p); p += 4;
+  p += 8;
+  const size_t npat = spl == 0xFFFFFFFFu ? 0 : spl;
+  if (npat > (1u << 20)) return false;
+  const size_t sl = 12 + 6 * npat;
+  if (!need(sl * 4)) return false;
+  for (size_t i = 0; i < sl; i++) {
+    const uint32_t v = rd32(b + p + 4 * i);
+    if (v >= tl || (v & (stride - 1))) return false;
+    if (i < 12) d.starts[i] = v;
+  }
+  p += sl * 4;
+  if (!need(4)) return false;
+  const uint32_t ms_len = rd32(b + p); p += 4;
+  if (ms_len > d.state_len) return false;
+  if (!need((size_t)ms_len * 8 + 8)) return false;
+  p += (size_t)ms_len * 8;
+  p += 4;
+  const uint32_t idlen = rd32(b + p); p += 4;
+  if (idlen > (1u << 24) || !need((size_t)idlen * 4)) return false;
+  p += (size_t)idlen * 4;
+  if (!need(32)) return false;
+  d.sp_max = rd32(b + p); d.quit_id = rd32(b + p + 4); d.min_match = rd32(b + p + 8); d.max_match = rd32(b + p + 12);
+  const uint32_t min_accel = rd32(b + p + 16), max_accel = rd32(b + p + 20), min_start = rd32(b + p + 24), max_start = rd32(b + p + 28);
+  p += 32;
+  if (d.min_match > d.max_match || min_accel > max_accel || min_start > max_start) return false;
+  if ((d.min_match == 0) != (d.max_match == 0)) return false;
+  if (d.max_match > d.sp_max || max_accel > d.sp_max || max_start > d.sp_max) return false;
+  if (tl && d.sp_max >= tl) return false;
+  {
+    const uint32_t nm = d.max_match ? ((d.max_match - d.min_match) >> d.stride2) + 1 : 0;
+    if (nm != ms_len) return false;
+  }
+  if (!need(4)) return false;
+  const uint32_t acc = rd32(b + p); p += 4;
+  if (acc > d.state_len || !need((size_t)acc * 8)) return false;
+  p += (size_t)acc * 8;
+  if (!need(32)) return false;
+  memcpy(d.quitset, b + p, 32);
+  d.quitset_nonempty = 0;
+  for (int i = 0; i < 32; i++) if (d.quitset[i]) d.quitset_nonempty = 1;
+  d.wide = tl > 65536 ? 1u : 0u;
+  d.valid = 1;
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int zke_dfa_register(zke_engine* e, const uint8_t* fwd, size_t fwd_len, const uint8_t* bwd, size_t bwd_len, uint32_t* out_id) {
+  if (!e || !out_id || (fwd_len && !fwd) || (bwd_len && !bwd)) return ZKE_E_ARG;
+  HIPCHK(e, hipSetDevice(e->device));
+  RegisteredDfa* rd = new RegisteredDfa();
+  HostDfa hf, hr;
+  const bool ok = parse_dfa_blob(fwd, fwd_len, hf) && parse_dfa_blob(bwd, bwd_len, hr);
+  rd->valid = ok;
+  if (ok) {
+    auto packed = [](const HostDfa& h) { return (((size_t)h.d.table_len * (h.d.wide ? 4 : 2)) + 15) & ~(size_t)15; };
+    const size_t fb = packed(hf), rb = packed(hr);
+    rd->lds_bytes = fb + rb;
+    int r = 0;
+    if ((r = rd->blob.ensure(fb + rb + 64)) || (r = rd->dev.ensure(sizeof(RegexDev)))) { delete rd; return fail(e, r, "hipMalloc"); }
+    std::vector<uint8_t> img(fb + rb + 64, 0);
+    auto pack = [&](const HostDfa& h, size_t off) {
+      if (h.d.wide) memcpy(img.data() + off, h.table.data(), h.table.size() * 4);
+      else { uint16_t* o = reinterpret_cast<uint16_t*>(img.data() + off); for (size_t i = 0; i < h.table.size(); i++) o[i] = (uint16_t)h.table[i]; }
+    };
+    pack(hf, 0); pack(hr, fb);
+    RegexDev rdv{};
+    rdv.fwd = hf.d; rdv.rev = hr.d;
+    rdv.fwd.table = (uint64_t)rd->blob.as<uint8_t>();
+    rdv.rev.table = (uint64_t)(rd->blob.as<uint8_t>() + fb);
+    hipError_t he = hipMemcpy(rd->blob.p, img.data(), img.size(), hipMemcpyHostToDevice);
+    if (he == hipSuccess) he = hipMemcpy(rd->dev.p, &rdv, sizeof rdv, hipMemcpyHostToDevice);
+    if (he != hipSuccess) { rd->blob.release(); rd->dev.release(); delete rd; return fail(e, ZKE_E_DEVICE, "dfa upload", he); }
+  }
+  e->dfas.push_back(rd);
+  *out_id = (uint32_t)(e->dfas.size() - 1);
+  return 0;
+}
+
+int zke_verify_batch_device(zke_engine* e, const zke_batch* in, uint64_t raw_total, uint64_t domain_total, uint64_t key_total,
+                            zke_result* out_dev, void* stream) {
+  (void)domain_total; (void)key_total;
+  if (!e || !in || (in->n && (!out_dev || !in->raw_blob || !in->raw_off || !in->domain_off || !in->key_off || !in->key_type)))
+    return ZKE_E_ARG;
+  HIPCHK(e, hipSetDevice(e->device));
+  // the part-id lists are small host arrays even in device mode
+  e->host_hdr_ids.assign(in->header_part_ids, in->header_part_ids + (in->with_regex ? in->n_header_parts : 0));
+  e->host_body_ids.assign(in->body_part_ids, in->body_part_ids + (in->with_regex ? in->n_body_parts : 0));
+  return run_device_pipeline(e, in, raw_total, out_dev, stream ? (hipStream_t)stream : e->stream, false);
+}
+
+int zke_verify_batch(zke_engine* e, const zke_batch* in, zke_result* out, zke_debug_out* dbg) {
+  if (!e || !in || (in->n && (!out || !in->raw_blob || !in->raw_off || !in->domain_blob || !in->domain_off || !in->key_blob ||
+                              !in->key_off || !in->key_type)))
+    return ZKE_E_ARG;
+  const uint32_t n = in->n;
+  if (n == 0) return 0;
+  HIPCHK(e, hipSetDevice(e->device));
+  hipStream_t s = e->stream;
+  const uint64_t raw_total = in->raw_off[n] - in->raw_off[0], dom_total = in->domain_off[n] - in->domain_off[0],
+                 key_total = in->key_off[n] - in->key_off[0];
+  const uint32_t P = in->with_regex ? in->n_header_parts + in->n_body_parts : 0;
+  const bool caps = P && in->cap_off;
+  const uint32_t n_caps = caps ? in->cap_off[(size_t)n * P] : 0;
+  const uint32_t cap_bytes = caps ? in->cap_str_off[n_caps] : 0;
+  int r = 0;
+  if ((r = e->in_raw.ensure(raw_total + 64)) || (r = e->in_raw_off.ensure((size_t)(n + 1) * 8)) ||
+      (r = e->in_dom.ensure(dom_total + 64)) || (r = e->in_dom_off.ensure((size_t)(n + 1) * 8)) ||
+      (r = e->in_key.ensure(key_total + 64)) || (r = e->in_key_off.ensure((size_t)(n + 1) * 8)) ||
+      (r = e->in_ktype.ensure(n)) || (r = e->in_extnull.ensure(n)) || (r = e->results.ensure((size_t)n * sizeof(zke_result))))
+    return fail(e, r, "input allocation");
+  if (caps && ((r = e->in_cap_off.ensure(((size_t)n * P + 1) * 4)) || (r = e->in_cap_str_off.ensure(((size_t)n_caps + 1) * 4)) ||
+               (r = e->in_cap_blob.ensure((size_t)cap_bytes + 64))))
+    return fail(e, r, "input allocation");
+
+  hipEvent_t h0 = e->ev_h2d[0], h1 = e->ev_h2d[1], d0 = e->ev_h2d[2], d1 = e->ev_h2d[3];
+  if (e->timing) (void)hipEventRecord(h0, s);
+  // rebase the CSR offsets to 0 on the way in
+  std::vector<uint64_t> ro(n + 1), dofs(n + 1), ko(n + 1);
+  for (uint32_t i = 0; i <= n; i++) { ro[i] = in->raw_off[i] - in->raw_off[0]; dofs[i] = in->domain_off[i] - in->domain_off[0]; ko[i] = in->key_off[i] - in->key_off[0]; }
+  if (raw_total) HIPCHK(e, hipMemcpyAsync(e->in_raw.p, in->raw_blob + in->raw_off[0], raw_total, hipMemcpyHostToDevice, s));
+  if (dom_total) HIPCHK(e, hipMemcpyAsync(e->in_dom.p, in->domain_blob + in->domain_off[0], dom_total, hipMemcpyHostToDevice, s));
+  if (key_total) HIPCHK(e, hipMemcpyAsync(e->in_key.p, in->key_blob + in->key_off[0], key_total, hipMemcpyHostToDevice, s));
+  HIPCHK(e, hipMemcpyAsync(e->in_raw_off.p, ro.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, s));
+  HIPCHK(e, hipMemcpyAsync(e->in_dom_off.p, dofs.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, s));
+  HIPCHK(e, hipMemcpyAsync(e->in_key_off.p, ko.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, s));
+  HIPCHK(e, hipMemcpyAsync(e->in_ktype.p, in->key_type, n, hipMemcpyHostToDevice, s));
+  if (in->ext_null) HIPCHK(e, hipMemcpyAsync(e->in_extnull.p, in->ext_null, n, hipMemcpyHostToDevice, s));
+  if (caps) {
+    HIPCHK(e, hipMemcpyAsync(e->in_cap_off.p, in->cap_off, ((size_t)n * P + 1) * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(e, hipMemcpyAsync(e->in_cap_str_off.p, in->cap_str_off, ((size_t)n_caps + 1) * 4, hipMemcpyHostToDevice, s));
+    if (cap_bytes) HIPCHK(e, hipMemcpyAsync(e->in_cap_blob.p, in->cap_blob, cap_bytes, hipMemcpyHostToDevice, s));
+  }
+  // the copies above read pageable host memory that goes out of scope (ro/dofs/ko): make them complete first
+  HIPCHK(e, hipStreamSynchronize(s));
+  if (e->timing) (void)hipEventRecord(h1, s);
+
+  zke_batch dv = *in;
+  dv.raw_blob = e->in_raw.as<uint8_t>(); dv.raw_off = e->in_raw_off.as<uint64_t>();
+  dv.domain_blob = e->in_dom.as<uint8_t>(); dv.domain_off = e->in_dom_off.as<uint64_t>();
+  dv.key_blob = e->in_key.as<uint8_t>(); dv.key_off = e->in_key_off.as<uint64_t>();
+  dv.key_type = e->in_ktype.as<uint8_t>();
+  dv.ext_null = in->ext_null ? e->in_extnull.as<uint8_t>() : nullptr;
+  dv.cap_off = caps ? e->in_cap_off.as<uint32_t>() : nullptr;
+  dv.cap_str_off = caps ? e->in_cap_str_off.as<uint32_t>() : nullptr;
+  dv.cap_blob = caps ? e->in_cap_blob.as<uint8_t>() : nullptr;
+  e->host_hdr_ids.assign(in->header_part_ids, in->header_part_ids + (in->with_regex ? in->n_header_parts : 0));
+  e->host_body_ids.assign(in->body_part_ids, in->body_part_ids + (in->with_regex ? in->n_body_parts : 0));
+  if ((r = run_device_pipeline(e, &dv, raw_total, e->results.as<zke_result>(), s, dbg && dbg->em))) return r;
+  if (e->timing) (void)hipEventRecord(d0, s);
+  HIPCHK(e, hipMemcpyAsync(out, e->results.p, (size_t)n * sizeof(zke_result), hipMemcpyDeviceToHost, s));
+  HIPCHK(e, hipStreamSynchronize(s));
+  if (e->timing) {
+    (void)hipEventRecord(d1, s);
+    (void)hipEventSynchronize(d1);
+    collect_timings(e);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, h0, h1); e->last.h2d_us = ms * 1000.f;
+    (void)hipEventElapsedTime(&ms, d0, d1); e->last.d2h_us = ms * 1000.f;
+  }
+
+  if (dbg) {   // parity intermediates: copy the scratch back and slice it on the host
+    std::vector<EmailMeta> meta(n), meta2;
+    HIPCHK(e, hipMemcpy(meta.data(), e->meta.p, (size_t)n * sizeof(EmailMeta), hipMemcpyDeviceToHost));
+    const size_t scratch_bytes = 2 * (size_t)raw_total + (size_t)(n + 1) * SCR_PER_EMAIL + 256;
+    std::vector<uint8_t> scr(scratch_bytes);
+    HIPCHK(e, hipMemcpy(scr.data(), e->scratch.p, scratch_bytes, hipMemcpyDeviceToHost));
+    std::vector<uint8_t> em, clean;
+    if (dbg->em) { em.resize((size_t)n * 512); HIPCHK(e, hipMemcpy(em.data(), e->em_dbg.p, em.size(), hipMemcpyDeviceToHost)); }
+    if (dbg->clean_body && in->with_regex) {
+      meta2.resize(n);
+      HIPCHK(e, hipMemcpy(meta2.data(), e->meta2.p, (size_t)n * sizeof(EmailMeta), hipMemcpyDeviceToHost));
+      clean.resize((size_t)raw_total + (size_t)(n + 1) * CLEAN_PER_EMAIL + 256);
+      HIPCHK(e, hipMemcpy(clean.data(), e->clean.p, clean.size(), hipMemcpyDeviceToHost));
+    }
+    auto put = [](uint8_t* base, size_t stride, uint32_t i, const uint8_t* src, size_t len) {
+      if (!base) return;
+      memset(base + (size_t)i * stride, 0, stride);
+      memcpy(base + (size_t)i * stride, src, std::min(len, stride));
+    };
+    for (uint32_t i = 0; i < n; i++) {
+      const EmailMeta& m = meta[i];
+      const uint32_t raw_len = (uint32_t)(ro[i + 1] - ro[i]);
+      const uint8_t* regA = scr.data() + host_scratch_off(ro.data(), i);
+      const uint8_t* regB = regA + (((size_t)raw_len + PRE_SLACK + 15) & ~(size_t)15);
+      const bool hashed = out[i].canon_header_len || out[i].canon_body_len || m.canon_full_len;
+      put(dbg->canon_header, dbg->canon_header_stride, i, regA, hashed ? out[i].canon_header_len : 0);
+      const uint8_t* body = m.body_src_is_raw ? in->raw_blob + in->raw_off[i] + m.body_off : regB;
+      put(dbg->canon_body, dbg->canon_body_stride, i, body, hashed ? m.canon_full_len : 0);
+      if (dbg->canon_body_full_len) dbg->canon_body_full_len[i] = hashed ? m.canon_full_len : 0;
+      if (dbg->em) put(dbg->em, dbg->em_stride, i, em.data() + (size_t)i * 512 + 512 - std::min<uint32_t>(512, e_k(out[i].rsa_bits)),
+                       std::min<uint32_t>(512, e_k(out[i].rsa_bits)));
+      if (dbg->clean_body && in->with_regex && meta2[i].state == ST_CAND)
+        put(dbg->clean_body, dbg->clean_body_stride, i, clean.data() + (ro[i] + (uint64_t)i * CLEAN_PER_EMAIL), meta2[i].hashed_len);
+      else if (dbg->clean_body)
+        put(dbg->clean_body, dbg->clean_body_stride, i, nullptr, 0);
+    }
+  }
+  return 0;
+}
+
+int zke_verify_email(zke_engine* e, const uint8_t* raw, size_t raw_len, const char* from_domain, size_t domain_len,
+                     const uint8_t* key, size_t key_len, uint32_t key_type, zke_result* out) {
+  if (!e || !out) return ZKE_E_ARG;
+  const uint64_t ro[2] = {0, raw_len}, dofs[2] = {0, domain_len}, ko[2] = {0, key_len};
+  const uint8_t kt = (uint8_t)key_type;
+  static const uint8_t dummy = 0;
+  zke_batch b{};
+  b.n = 1;
+  b.raw_blob = raw ? raw : &dummy; b.raw_off = ro;
+  b.domain_blob = from_domain ? reinterpret_cast<const uint8_t*>(from_domain) : &dummy; b.domain_off = dofs;
+  b.key_blob = key ? key : &dummy; b.key_off = ko;
+  b.key_type = &kt;
+  return zke_verify_batch(e, &b, out, nullptr);
+}
+
+}  // extern "C"

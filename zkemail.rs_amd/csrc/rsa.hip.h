@@ -37,7 +37,6 @@ static_assert(sizeof(RsaJob) == 1056, "RsaJob layout");
 
 enum : uint32_t {
   RSA_F_ACTIVE = 1,             // run the modexp
-  RSA_F_LEN_MISMATCH = 2,       // sig_len != k  -> verification error without a modexp
 };
 
 // ---- cross-lane helpers -------------------------------------------------------------
@@ -218,7 +217,7 @@ __global__ __launch_bounds__(256) void rsa_verify_kernel(const RsaJob* __restric
   }
   uint32_t ok = 0;
   const bool odd = (__builtin_amdgcn_readfirstlane(nn.v[0]) & 1) != 0;
-  const bool lenok = !(flags & RSA_F_LEN_MISMATCH);
+  const bool lenok = J->sig_len == k;             // rsa 0.9.6 pkcs1v15::verify: sig_len != pub_key.size() -> Err
   Big<NL> em;
 #pragma unroll
   for (int q = 0; q < NL; q++) em.v[q] = 0;

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void sha256_batch_kernel(const ShaJob* __restr
   if (m < n) {
     ShaJob j = jobs[m];
     my_src = j.src; my_dst = j.dst; my_len = j.len;
-    my_nblk = (my_len + 9 + 63) >> 6;
+    my_nblk = my_dst ? (my_len + 9 + 63) >> 6 : 0;      // dst == 0 marks an inactive job
   }
   *(uint64_t*)(desc + lane * 16) = my_src;
   *(uint32_t*)(desc + lane * 16 + 8) = my_len;
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void sha256_batch_kernel(const ShaJob* __restr
     }
     __builtin_amdgcn_wave_barrier();
   }
-  if (m < n) {
+  if (m < n && my_dst) {
     uint32_t* out = (uint32_t*)my_dst;      // digests are 4-byte aligned (result records / engine buffers)
 #pragma unroll
     for (int i = 0; i < 8; i++) out[i] = __builtin_bswap32(st[i]);
