@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py — emails verified/sec (witness generation) on MI355X, one process per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path (verify_email: parse -> canonicalise -> SHA-256 -> RSA-2048 ->
+verdict) over one batch of BASELINE.json configs[1]: 1 024 synthetic DKIM-signed e-mails, 4 KB
+canonical body, RSA-2048, DKIM only.  Inputs are resident in HBM before the timed region; every
+rank verifies its own batch (independent e-mails: weak scaling, no data-path collective) and the
+fixed-size result records are all-gathered over RCCL inside the step when N > 1.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` (the SHA-256
+batch kernel, HIP-event timed on the launch stream) and `cpu_baseline` (the CPU oracle — a port,
+not the Rust reference — on this box's host cores).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c4shard", "c5"],
+                    help="c2 = BASELINE configs[1] (default); c4shard = one GPU's shard of configs[3]; c5 = configs[4] shape")
+    ap.add_argument("--batch", type=int, default=0, help="override e-mails per step (default: the config's batch)")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU baseline sample budget per leg")
+    ap.add_argument("--no-cpu", action="store_true")
+    return ap.parse_args()
+
+
+def device_batch(torch, wl_batch, dev):
+    """Move a PackedBatch to HBM as uint8 / int64 tensors and build a zke_batch of device pointers."""
+    from zkemail_rs_amd import _abi as A
+
+    def t(arr):
+        return torch.from_numpy(np.ascontiguousarray(arr).view(np.uint8).copy()).to(dev)
+
+    keep = {
+        "raw": t(np.concatenate([wl_batch.raw_blob, np.zeros(64, np.uint8)])), "raw_off": t(wl_batch.raw_off),
+        "dom": t(np.concatenate([wl_batch.domain_blob, np.zeros(64, np.uint8)])), "dom_off": t(wl_batch.domain_off),
+        "key": t(np.concatenate([wl_batch.key_blob, np.zeros(64, np.uint8)])), "key_off": t(wl_batch.key_off),
+        "ktype": t(wl_batch.key_type), "ext": t(wl_batch.ext_null),
+    }
+    b = A.zke_batch()
+    b.n = wl_batch.n
+    b.raw_blob = keep["raw"].data_ptr(); b.raw_off = keep["raw_off"].data_ptr()
+    b.domain_blob = keep["dom"].data_ptr(); b.domain_off = keep["dom_off"].data_ptr()
+    b.key_blob = keep["key"].data_ptr(); b.key_off = keep["key_off"].data_ptr()
+    b.key_type = keep["ktype"].data_ptr(); b.ext_null = keep["ext"].data_ptr()
+    b.with_regex = 0
+    totals = (int(wl_batch.raw_off[-1]), int(wl_batch.domain_off[-1]), int(wl_batch.key_off[-1]))
+    return b, keep, totals
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    import torch
+    import torch.distributed as dist
+
+    import zkemail_rs_amd as z
+    from zkemail_rs_amd import _abi as A
+    from zkemail_rs_amd import synth
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    # ---- workload: every rank gets its own seeded batch of the same shape (weak scaling)
+    cfgs = {
+        "c2": dict(n=1024, body_len=4096, rsa_bits=2048, n_keys=16),
+        "c4shard": dict(n=8192, body_len=65536, rsa_bits=2048, n_keys=16),
+        "c5": dict(n=2048, body_len=4096, rsa_bits=4096, n_keys=16, qp_frac=0.05),
+    }
+    cfg = dict(cfgs[args.workload])
+    if args.batch:
+        cfg["n"] = args.batch
+    t0 = time.time()
+    wl = synth.make_workload(args.workload, seed=1000 + rank, **cfg)
+    gen_s = time.time() - t0
+    packed = A.PackedBatch(wl.emails)
+    cb, keep, totals = device_batch(torch, packed, dev)
+    n = packed.n
+    results = torch.zeros(n * 192, dtype=torch.uint8, device=dev)
+    gathered = torch.zeros(world * n * 192, dtype=torch.uint8, device=dev) if world > 1 else None
+
+    eng = z.Engine(device=local_rank)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        eng.verify_batch_device(cb, totals[0], totals[1], totals[2], results.data_ptr(), stream)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, results)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # ---- correctness of what was timed (outside the timed region)
+    rec = results.cpu().numpy().view(A.RESULT_DTYPE)
+    n_ok = int((rec["status"] == 0).sum())
+    if n_ok != n:
+        raise SystemExit(f"rank {rank}: {n - n_ok} of {n} synthetic e-mails did not verify — benchmark invalid")
+    for i in range(0, n, max(1, n // 16)):
+        it = wl.inter[i]
+        assert bytes(rec[i]["body_hash"]) == it["body_hash"] and bytes(rec[i]["header_hash"]) == it["header_hash"]
+    if world > 1:
+        allrec = gathered.cpu().numpy().view(A.RESULT_DTYPE)
+        assert int((allrec["status"] == 0).sum()) == world * n
+
+    # ---- per-kernel device time, HIP events on the launch stream (second pass, same steps)
+    eng.set_timing(True)
+    acc = {}
+    tsteps = min(args.steps, 50)
+    for _ in range(tsteps):
+        step()
+        torch.cuda.synchronize()
+        tm = eng.timings()
+        for k, v in tm.items():
+            acc[k] = acc.get(k, 0.0) + v
+    eng.set_timing(False)
+    kern = {k: v / tsteps for k, v in acc.items()}
+
+    emails_per_s = world * n * args.steps / dt
+    # SHA-256 launch: algorithmic bytes = every byte hashed once + 32 B per digest
+    hashed = wl.body_bytes + sum(len(it["canon_header"]) for it in wl.inter) + \
+        sum(len(e.from_domain.encode()) + len(e.public_key.key) for e in wl.emails)
+    sha_bytes = hashed + 32 * 4 * n
+    sha_s = kern["sha_us"] * 1e-6
+    roof = {
+        "bound": "hbm", "kernel": "sha256_batch_kernel<256>", "achieved": round(sha_bytes / sha_s / 1e9, 3) if sha_s > 0 else None,
+        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(sha_bytes / sha_s / 1e9 / HBM_PEAK_GBS, 5) if sha_s > 0 else None,
+        "traffic": None, "bytes_per_launch": sha_bytes, "launch_us": round(kern["sha_us"], 2),
+        "note": "SHA-256 on CDNA4 is integer-VALU bound (~1.4k VALU per 64-B block per lane -> ~3.3 TB/s ceiling), "
+                "and a 1024-message launch is bounded by the 65-block dependency chain of one message; see DESIGN.md",
+    }
+
+    out = {
+        "metric": "emails verified/sec (witness gen)", "value": round(emails_per_s, 1), "unit": "emails/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[1]: batch {n} e-mails, 4 KB body, RSA-2048, DKIM-only verify_email"
+                   if args.workload == "c2" else f"{args.workload}: {cfg}",
+                   "emails_per_step_per_gpu": n, "body_bytes": cfg["body_len"], "rsa_bits": cfg["rsa_bits"],
+                   "inputs": "HBM-resident raw e-mails", "collective": "all_gather of 192-B result records (RCCL)" if world > 1 else "none"},
+        "roofline": roof,
+        "kernels_us": {k: round(v, 2) for k, v in kern.items()},
+        "workload_gen_s": round(gen_s, 2),
+    }
+
+    # ---- CPU baseline: the oracle (port) on this box's host cores, rank 0, N = 1 only
+    if rank == 0 and world == 1 and not args.no_cpu:
+        import oracle_lib
+        orc = oracle_lib.load()
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+
+        def cpu_leg(threads):
+            reps, t_used = 0, 0.0
+            t_start = time.perf_counter()
+            while t_used < args.cpu_seconds:
+                r = orc.verify_batch(packed, threads=threads)
+                reps += 1
+                t_used = time.perf_counter() - t_start
+            assert (r["status"] == 0).all()
+            return reps * n / t_used, reps
+
+        one, reps1 = cpu_leg(1)
+        allc, repsn = cpu_leg(cores)
+        out["cpu_baseline"] = {
+            "value": round(allc, 1), "unit": "emails/s", "cores": cores, "kind": "port",
+            "sample": f"{repsn} x the same {n}-e-mail batch, one worker thread per core ({args.cpu_seconds:.0f} s budget); "
+                      f"CPU restatement of the zkemail_core path (oracle/zke_oracle.c, SHA-NI {'on' if orc.lib.zko_sha256_uses_shani() else 'off'})",
+            "single_thread_value": round(one, 1),
+        }
+        out["gpu_over_cpu"] = round(emails_per_s / allc, 2)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

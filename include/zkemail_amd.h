@@ -173,6 +173,10 @@ typedef struct zke_debug_out {
 
 typedef struct zke_options {
   int32_t  device;        /* HIP device ordinal; -1 = current */
+  /* reserved[0]: max signature rounds in host mode (default 4; rounds beyond the first run only while some
+   *              e-mail's earlier same-domain signature failed and a later one exists).
+   * reserved[1]: signature rounds in device mode (default 1; fixed, nothing is read back).  An e-mail that
+   *              needs more reports ZKE_UNSUPPORTED / ZKE_D_U_TOO_MANY_SIGS.  Others: 0. */
   uint32_t reserved[7];
 } zke_options;
 

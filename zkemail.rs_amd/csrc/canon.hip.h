@@ -116,7 +116,7 @@ __global__ __launch_bounds__(64) void canon_body_kernel(CanonArgs A) {
 }
 
 // ---- verdict of one signature round (thread per e-mail) -------------------------------
-struct FinArgs { BatchDev b; const uint32_t* rsa_ok; uint32_t round, max_rounds; };
+struct FinArgs { BatchDev b; const uint32_t* rsa_ok; uint32_t round, max_rounds; uint32_t* pending; };
 
 __global__ void finalize_kernel(FinArgs A) {
   const BatchDev& B = A.b;
@@ -154,7 +154,11 @@ __global__ void finalize_kernel(FinArgs A) {
       R->sig_index = M->cand_sig_index;
     } else if (M->cand_total > A.round + 1) {
       if (unsupported_here) M->unsupported = err;
-      if (A.round + 1 < A.max_rounds) { M->state = ST_PENDING; M->cand_err = err; R->status = ZKE_DKIM_NOT_PASS; R->detail = err; return; }
+      if (A.round + 1 < A.max_rounds) {
+        M->state = ST_PENDING; M->cand_err = err; R->status = ZKE_DKIM_NOT_PASS; R->detail = err;
+        atomicAdd(A.pending, 1u);
+        return;
+      }
       status = ZKE_UNSUPPORTED; detail = ZKE_D_U_TOO_MANY_SIGS;
       R->sig_index = M->last_touched_sig;
     } else {

@@ -68,8 +68,10 @@ struct zke_engine {
   DevBuf in_cap_off, in_cap_str_off, in_cap_blob;
   DevBuf results, meta, rsa_jobs, sha_jobs, rsa_ok, em_dbg, scratch_off, scratch, clean, meta2, scratch2, parts;
   DevBuf misc;   // building-block entry points
+  DevBuf pending; // device counter: e-mails that need another signature round
   std::vector<RegisteredDfa*> dfas;
-  uint32_t max_sig_rounds = 2;
+  uint32_t max_sig_rounds = 4;      // host mode: upper bound, rounds are added only while e-mails are pending
+  uint32_t device_mode_rounds = 1;  // device mode: fixed (no read-back)
 };
 
 namespace {
@@ -141,6 +143,7 @@ int zke_engine_create(const zke_options* opt, zke_engine** out) {
   for (auto& ev : e->ev) if (hipEventCreate(&ev) != hipSuccess) { delete e; return ZKE_E_DEVICE; }
   for (auto& ev : e->ev_h2d) if (hipEventCreate(&ev) != hipSuccess) { delete e; return ZKE_E_DEVICE; }
   if (opt && opt->reserved[0]) e->max_sig_rounds = std::min<uint32_t>(opt->reserved[0], 8);
+  if (opt && opt->reserved[1]) e->device_mode_rounds = std::min<uint32_t>(opt->reserved[1], 8);
   *out = e;
   return 0;
 }
@@ -152,7 +155,7 @@ void zke_engine_destroy(zke_engine* e) {
   DevBuf* bufs[] = {&e->in_raw, &e->in_raw_off, &e->in_dom, &e->in_dom_off, &e->in_key, &e->in_key_off, &e->in_ktype,
                     &e->in_extnull, &e->in_cap_off, &e->in_cap_str_off, &e->in_cap_blob, &e->results, &e->meta,
                     &e->rsa_jobs, &e->sha_jobs, &e->rsa_ok, &e->em_dbg, &e->scratch_off, &e->scratch, &e->clean,
-                    &e->meta2, &e->misc, &e->scratch2, &e->parts};
+                    &e->meta2, &e->misc, &e->scratch2, &e->parts, &e->pending};
   for (auto* b : bufs) b->release();
   for (auto* d : e->dfas) { d->blob.release(); d->dev.release(); delete d; }
   for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
@@ -177,6 +180,10 @@ int zke_set_timing(zke_engine* e, int enabled) {
 
 int zke_get_timings(zke_engine* e, zke_timings* t) {
   if (!e || !t) return ZKE_E_ARG;
+  if (e->timing && e->timed_marks > 0) {     // device-mode batches: the events are read once their stream has drained
+    HIPCHK(e, hipEventSynchronize(e->ev[e->timed_marks - 1]));
+    collect_timings(e);
+  }
   *t = e->last;
   return 0;
 }

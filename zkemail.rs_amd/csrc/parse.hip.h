@@ -551,7 +551,13 @@ __global__ __launch_bounds__(64) void parse_kernel(ParseArgs A) {
   zke_result* R = B.results + i;
   RsaJob* J = B.rsa + i;
   const uint32_t round = A.round;
-  if (round > 0 && M->state != ST_PENDING) return;
+  if (round > 0 && A.mode == 0) {
+    // later signature rounds: retire this e-mail's jobs of the previous round first, so the SHA / RSA
+    // launches of this round only touch e-mails that are still pending
+    if (lane < 4) { ShaJob z{0, 0, 0, 0}; B.sha[(size_t)lane * B.n_pad + i] = z; }
+    if (lane == 0) J->flags = 0;
+    if (M->state != ST_PENDING) return;
+  }
 
   const uint64_t r0 = B.raw_off[i], r1 = B.raw_off[i + 1];
   const Str raw = mkstr(B.raw + r0, (uint32_t)(r1 - r0));
@@ -594,9 +600,6 @@ __global__ __launch_bounds__(64) void parse_kernel(ParseArgs A) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     if (lane == 0) R->regex_part = 0xFFFFFFFFu;
     if (r1 - r0 >= (1ull << 31)) { finish(ZKE_UNSUPPORTED, ZKE_D_U_EMAIL_TOO_LARGE); return; }
-  } else {
-    for (uint32_t k = 0; k < 4; k++) sha_job(k, nullptr, 0, nullptr);
-    if (lane == 0) J->flags = 0;
   }
 
   // ---- mailparse::parse_mail (core/src/email.rs:26)

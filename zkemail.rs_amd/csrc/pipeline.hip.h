@@ -30,8 +30,10 @@ struct StageTimer {
 };
 
 // The device pipeline.  Every pointer in `in` / out_dev is device memory.
+// Signature rounds [round_begin, round_end) of verify_email_with_key run here; the regex stage runs when
+// `with_regex_stage` is set (after the last round the caller intends to run).
 int run_device_pipeline(zke_engine* e, const zke_batch* in, uint64_t raw_total, zke_result* out_dev, hipStream_t s,
-                        bool want_em) {
+                        bool want_em, uint32_t round_begin, uint32_t round_end, uint32_t max_rounds, bool with_regex_stage) {
   const uint32_t n = in->n;
   if (n == 0) return 0;
   const uint32_t n_pad = (n + 63) & ~63u;
@@ -40,7 +42,7 @@ int run_device_pipeline(zke_engine* e, const zke_batch* in, uint64_t raw_total, 
   const size_t scratch_bytes = 2 * (size_t)raw_total + (size_t)(n + 1) * SCR_PER_EMAIL + 256;
   if ((r = e->meta.ensure((size_t)n * sizeof(EmailMeta))) || (r = e->rsa_jobs.ensure((size_t)n * sizeof(RsaJob))) ||
       (r = e->sha_jobs.ensure((size_t)4 * n_pad * sizeof(ShaJob))) || (r = e->rsa_ok.ensure((size_t)n * 4)) ||
-      (r = e->scratch_off.ensure((size_t)(n + 1) * 16)) || (r = e->scratch.ensure(scratch_bytes)))
+      (r = e->scratch_off.ensure((size_t)(n + 1) * 16)) || (r = e->scratch.ensure(scratch_bytes)) || (r = e->pending.ensure(64)))
     return fail(e, r, "workspace allocation");
   if (want_em && (r = e->em_dbg.ensure((size_t)n * 512))) return fail(e, r, "workspace allocation");
   if (in->with_regex) {
@@ -54,9 +56,12 @@ int run_device_pipeline(zke_engine* e, const zke_batch* in, uint64_t raw_total, 
 
   StageTimer tm(e, s);
   tm.mark();
-  hipLaunchKernelGGL(offsets_kernel, dim3((n + 1 + 255) / 256), dim3(256), 0, s, in->raw_off, n, scratch_off, clean_off);
-  // jobs of the padding lanes of the last wave of each kind must read as inactive
-  HIPCHK(e, hipMemsetAsync(e->sha_jobs.p, 0, (size_t)4 * n_pad * sizeof(ShaJob), s));
+  if (round_begin == 0) {
+    hipLaunchKernelGGL(offsets_kernel, dim3((n + 1 + 255) / 256), dim3(256), 0, s, in->raw_off, n, scratch_off, clean_off);
+    // jobs of the padding lanes of the last wave of each kind must read as inactive
+    HIPCHK(e, hipMemsetAsync(e->sha_jobs.p, 0, (size_t)4 * n_pad * sizeof(ShaJob), s));
+    HIPCHK(e, hipMemsetAsync(e->pending.p, 0, 8, s));
+  }
 
   BatchDev B{};
   B.n = n;
@@ -73,8 +78,8 @@ int run_device_pipeline(zke_engine* e, const zke_batch* in, uint64_t raw_total, 
   B.scratch_off = scratch_off;
   B.meta_verify = nullptr;
 
-  const uint32_t rounds = std::max<uint32_t>(1, e->max_sig_rounds);
-  for (uint32_t round = 0; round < rounds; round++) {
+  const uint32_t rounds = max_rounds;
+  for (uint32_t round = round_begin; round < round_end; round++) {
     ParseArgs pa{B, round, 0};
     hipLaunchKernelGGL(parse_kernel, dim3(n), dim3(64), 0, s, pa);
     if (round == 0) tm.mark();
@@ -87,13 +92,13 @@ int run_device_pipeline(zke_engine* e, const zke_batch* in, uint64_t raw_total, 
                         sizeof(zke_result), e->rsa_ok.as<uint32_t>(), want_em ? e->em_dbg.as<uint8_t>() : nullptr, s, true)))
       return r;
     if (round == 0) tm.mark();
-    FinArgs fa{B, e->rsa_ok.as<uint32_t>(), round, rounds};
+    FinArgs fa{B, e->rsa_ok.as<uint32_t>(), round, rounds, e->pending.as<uint32_t>()};
     hipLaunchKernelGGL(finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, s, fa);
     if (round == 0) tm.mark();
   }
   HIPCHK(e, hipGetLastError());
 
-  if (in->with_regex) {
+  if (in->with_regex && with_regex_stage) {
     // canonicalize_signed_email (circuits.rs:34-35): first DKIM-Signature header, own scratch unless it is the verified one
     BatchDev B2 = B;
     B2.meta = e->meta2.as<EmailMeta>();
@@ -104,7 +109,7 @@ int run_device_pipeline(zke_engine* e, const zke_batch* in, uint64_t raw_total, 
     CanonArgs ca{B2, 1};
     hipLaunchKernelGGL(canon_body_kernel, dim3(n), dim3(64), 0, s, ca);
     QpArgs qa{B2, B.meta, e->clean.as<uint8_t>(), clean_off, B.scratch, B.scratch_off};
-    if (in->n_body_parts) hipLaunchKernelGGL(qp_kernel, dim3(n), dim3(64), 0, s, qa);
+    hipLaunchKernelGGL(qp_kernel, dim3(n), dim3(64), 0, s, qa);    // circuits.rs:37 runs whether or not body parts exist
     tm.mark();
     for (uint32_t p = 0; p < P; p++) {
       const bool is_body = p >= in->n_header_parts;
@@ -287,7 +292,9 @@ int zke_verify_batch_device(zke_engine* e, const zke_batch* in, uint64_t raw_tot
   // the part-id lists are small host arrays even in device mode
   e->host_hdr_ids.assign(in->header_part_ids, in->header_part_ids + (in->with_regex ? in->n_header_parts : 0));
   e->host_body_ids.assign(in->body_part_ids, in->body_part_ids + (in->with_regex ? in->n_body_parts : 0));
-  return run_device_pipeline(e, in, raw_total, out_dev, stream ? (hipStream_t)stream : e->stream, false);
+  // device mode runs a fixed number of signature rounds (options.reserved[1], default 1) without reading anything back
+  const uint32_t rounds = e->device_mode_rounds;
+  return run_device_pipeline(e, in, raw_total, out_dev, stream ? (hipStream_t)stream : e->stream, false, 0, rounds, rounds, true);
 }
 
 int zke_verify_batch(zke_engine* e, const zke_batch* in, zke_result* out, zke_debug_out* dbg) {
@@ -347,7 +354,30 @@ int zke_verify_batch(zke_engine* e, const zke_batch* in, zke_result* out, zke_de
   dv.cap_blob = caps ? e->in_cap_blob.as<uint8_t>() : nullptr;
   e->host_hdr_ids.assign(in->header_part_ids, in->header_part_ids + (in->with_regex ? in->n_header_parts : 0));
   e->host_body_ids.assign(in->body_part_ids, in->body_part_ids + (in->with_regex ? in->n_body_parts : 0));
-  if ((r = run_device_pipeline(e, &dv, raw_total, e->results.as<zke_result>(), s, dbg && dbg->em))) return r;
+  // Signature rounds: round r tries every e-mail's r-th same-domain signature.  Almost every e-mail is decided
+  // in round 0; the device counts the undecided ones and the host adds rounds only while that count is non-zero.
+  const uint32_t max_rounds = std::max<uint32_t>(1, e->max_sig_rounds);
+  const bool want_em = dbg && dbg->em;
+  uint32_t round = 0;
+  for (;;) {
+    const bool last_possible = round + 1 >= max_rounds;
+    // the regex stage must follow the final verdicts: run it with this round only if no further round can follow
+    if ((r = run_device_pipeline(e, &dv, raw_total, e->results.as<zke_result>(), s, want_em, round, round + 1, max_rounds,
+                                 last_possible)))
+      return r;
+    if (last_possible) break;
+    uint32_t pending = 0;
+    HIPCHK(e, hipMemcpyAsync(&pending, e->pending.p, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(e, hipStreamSynchronize(s));
+    if (pending == 0) {
+      if (in->with_regex && (r = run_device_pipeline(e, &dv, raw_total, e->results.as<zke_result>(), s, want_em, round + 1,
+                                                     round + 1, max_rounds, true)))
+        return r;
+      break;
+    }
+    HIPCHK(e, hipMemsetAsync(e->pending.p, 0, 8, s));
+    round++;
+  }
   if (e->timing) (void)hipEventRecord(d0, s);
   HIPCHK(e, hipMemcpyAsync(out, e->results.p, (size_t)n * sizeof(zke_result), hipMemcpyDeviceToHost, s));
   HIPCHK(e, hipStreamSynchronize(s));

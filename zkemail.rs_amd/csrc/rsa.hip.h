@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void rsa_verify_kernel(const RsaJob* __restric
     ok = match ? 1u : 0u;
   }
   if (lane == 0) ok_out[job] = ok;
-  if (em_out) {
+  if (em_out && (flags & RSA_F_ACTIVE)) {     // inactive jobs (later signature rounds) leave the slot alone
 #pragma unroll
     for (int q = 0; q < NL; q++) {
       const uint32_t limb = q * 64 + lane;

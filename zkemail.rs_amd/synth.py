@@ -340,3 +340,91 @@ CONFIGS = {
     "c4": dict(n=65536, body_len=65536, rsa_bits=2048, n_keys=16, seed=4),
     "c5": dict(n=16384, body_len=4096, rsa_bits=4096, n_keys=16, seed=5, qp_frac=0.05),
 }
+
+
+# ------------------------------------------------------------------ regex workloads (configs 3 and 5)
+HEADER_PATTERNS = [   # over the canonical (relaxed) header preimage; shape of helpers/README.md:22-33
+    (r"from:[^\r\n]*<([a-z]+)@example\.com>\r\n", [1]),
+    (r"subject:([^\r\n]+)\r\n", [1]),
+]
+BODY_PATTERNS = [     # over the canonical body with QP soft breaks removed
+    (r"ZKE-ORDER-([0-9]{8});", [1]),
+    (r"ZKE-TOKEN-([a-f0-9]{12})!", [1]),
+]
+
+
+def inject_marker(body: bytes, rng: np.random.Generator, marker: bytes, split: bool, used: set) -> bytes:
+    """Overwrite part of one (or, with a QP soft break, two consecutive) 76-column lines with `marker`,
+    keeping every length.  With ``split`` the marker straddles a ``=CRLF`` soft line break."""
+    lines = body.split(b"\r\n")
+    cand = [i for i in range(len(lines) - 2) if len(lines[i]) >= 60 and len(lines[i + 1]) >= 60
+            and i not in used and i + 1 not in used and not lines[i].endswith(b"=") and not lines[i + 1].endswith(b"=")
+            and (i == 0 or not lines[i - 1].endswith(b"="))]
+    if not cand:
+        raise ValueError("body too small for a marker")
+    i = cand[int(rng.integers(0, len(cand)))]
+    used.update((i, i + 1))
+    if split:
+        j = int(rng.integers(1, len(marker)))
+        a, b = marker[:j], marker[j:]
+        la = lines[i]
+        lines[i] = la[:len(la) - len(a) - 1] + a + b"="
+        lines[i + 1] = b + lines[i + 1][len(b):]
+        # the byte in front of the marker must not be WSP-before-nothing issues: it is plain text already
+    else:
+        la = lines[i]
+        lines[i] = la[:5] + marker + la[5 + len(marker):]
+    return b"\r\n".join(lines)
+
+
+def make_regex_workload(name: str, n: int, body_len: int, rsa_bits: int = 2048, n_keys: int = 16, seed: int = 3,
+                        n_header_parts: int = 2, n_body_parts: int = 0, qp_frac: float = 0.0, fail_frac: float = 0.0):
+    """EmailWithRegex batch sharing one part list (BASELINE configs[2] / configs[4] shape).  Returns
+    (inputs, workload, expect) where expect[i] is None for a passing e-mail or 'header'/'body'."""
+    from . import regex_compile as rc
+    from ._abi import CompiledRegex, EmailWithRegex, RegexInfo
+    rng = np.random.default_rng(seed)
+    keys = keys_of(rsa_bits, n_keys)
+    hp = HEADER_PATTERNS[:n_header_parts]
+    bp = BODY_PATTERNS[:n_body_parts]
+    hdfa = [rc.create_dfa(p) for p, _ in hp]
+    bdfa = [rc.create_dfa(p) for p, _ in bp]
+    hrx = [re.compile(p.encode()) for p, _ in hp]
+    brx = [re.compile(p.encode()) for p, _ in bp]
+    inputs, emails, inter, expect = [], [], [], []
+    for i in range(n):
+        key = keys[i % len(keys)]
+        body = ascii_body(rng, body_len, qp_frac=qp_frac)
+        used: set = set()
+        fail = None
+        if fail_frac and rng.random() < fail_frac:
+            fail = "body" if (bp and (rng.random() < 0.5 or n_header_parts < 2)) else ("header" if n_header_parts >= 2 else None)
+        for k, (p, _) in enumerate(bp):
+            if k == 0:
+                marker = b"ZKE-ORDER-%08d;" % int(rng.integers(0, 10**8))
+            else:
+                marker = b"ZKE-TOKEN-%012x!" % int(rng.integers(0, 16**12))
+            body = inject_marker(body, rng, marker, split=bool(qp_frac) and rng.random() < 0.5, used=used)
+            if fail == "body" and k == 0:      # a second occurrence: find_iter().count() == 2
+                body = inject_marker(body, rng, marker, split=False, used=used)
+        hs = std_headers(rng, i, "example.com", pad_to=760)
+        if fail == "header":                   # two Subject headers are both signed below -> two matches
+            hs.append((b"Subject", b"second subject line"))
+        spec = SignSpec(domain="example.com")
+        if fail == "header":
+            spec.signed = ("from", "to", "subject", "subject", "date", "message-id")
+        raw, it = sign_email(hs, body, key, spec)
+        em = Email("example.com", raw, PublicKey(key.pkcs1_der, "rsa"))
+        clean = it["canon_body"].replace(b"=\r\n", b"")
+        hparts, bparts = [], []
+        for (p, ci), d, rx in zip(hp, hdfa, hrx):
+            m = rx.search(it["canon_header"])
+            hparts.append(CompiledRegex(d, [m.group(g).decode() for g in ci] if m else ["?"]))
+        for (p, ci), d, rx in zip(bp, bdfa, brx):
+            m = rx.search(clean)
+            bparts.append(CompiledRegex(d, [m.group(g).decode() for g in ci] if m else ["?"]))
+        it["clean_body"] = clean + b"\0" * (len(it["canon_body"]) - len(clean))
+        inputs.append(EmailWithRegex(em, RegexInfo(hparts or None, bparts or None)))
+        emails.append(em); inter.append(it); expect.append(fail)
+    wl = Workload(name, emails, inter, sum(x["hashed_body_len"] for x in inter), sum(len(e.raw_email) for e in emails))
+    return inputs, wl, expect
