@@ -1,0 +1,40 @@
+// Exercises include/zkemail_core.hpp (the C++ mirror of zkemail_core's API) end to end.
+// usage: mirror_test <raw.eml> <key.der> <from_domain> [fwd.dfa bwd.dfa capture]
+// prints "OK <from_domain_hash hex> <public_key_hash hex> [matches...]" or "PANIC <status> <detail>"
+#include <cstdio>
+#include <fstream>
+#include <iterator>
+
+#include "zkemail_core.hpp"
+
+static std::vector<uint8_t> slurp(const char* p) {
+  std::ifstream f(p, std::ios::binary);
+  return std::vector<uint8_t>(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+}
+static void hex(const std::vector<uint8_t>& v) { for (uint8_t b : v) std::printf("%02x", b); }
+
+int main(int argc, char** argv) {
+  if (argc < 4) return 2;
+  zkemail::Email em;
+  em.raw_email = slurp(argv[1]);
+  em.public_key = {slurp(argv[2]), "rsa"};
+  em.from_domain = argv[3];
+  try {
+    if (argc >= 7) {
+      zkemail::EmailWithRegex in{em, {}};
+      zkemail::CompiledRegex cr{{slurp(argv[4]), slurp(argv[5])}, std::vector<std::string>{argv[6]}};
+      in.regex_info.header_parts = std::vector<zkemail::CompiledRegex>{cr};
+      auto out = zkemail::verify_email_with_regex(in);
+      std::printf("OK "); hex(out.email.from_domain_hash); std::printf(" "); hex(out.email.public_key_hash);
+      for (auto& m : out.regex_matches) std::printf(" [%s]", m.c_str());
+      std::printf("\n");
+    } else {
+      auto out = zkemail::verify_email(em);
+      std::printf("OK "); hex(out.from_domain_hash); std::printf(" "); hex(out.public_key_hash); std::printf("\n");
+    }
+  } catch (const zkemail::VerifyPanic& p) {
+    std::printf("PANIC %u %u\n", p.status, p.detail);
+    return 1;
+  }
+  return 0;
+}

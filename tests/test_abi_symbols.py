@@ -1,0 +1,69 @@
+"""CPU (-m "not gpu"): the C-ABI shared library builds for gfx950, loads without a GPU and exports every
+function include/zkemail_amd.h declares; struct layouts in the ctypes mirror match the header; without a
+GPU the product refuses to run (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import zkemail_rs_amd as z
+from zkemail_rs_amd import _abi as A
+from zkemail_rs_amd import build, engine
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "zkemail_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(zke_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    build.build_engine()
+    lib = C.CDLL(build.ENGINE_SO)
+    names = declared_functions()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in zkemail_amd.h but not exported"
+    assert set(engine.EXPORTED_SYMBOLS) == set(names)
+    lib.zke_version.restype = C.c_char_p
+    assert b"gfx950" in lib.zke_version()
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(A.zke_result) == 192 and A.RESULT_DTYPE.itemsize == 192
+    for name, off in (("status", 0), ("from_domain_hash", 32), ("public_key_hash", 64), ("body_hash", 96),
+                      ("header_hash", 128), ("regex_part", 160), ("rsa_bits", 176)):
+        assert getattr(A.zke_result, name).offset == off == A.RESULT_DTYPE.fields[name][1]
+    assert C.sizeof(A.zke_options) == 32
+    # status / detail constants agree with the header
+    src = open(os.path.join(ROOT, "include", "zkemail_amd.h")).read()
+    for m in re.finditer(r"\b(ZKE_(?:D_)?[A-Z0-9_]+)\s*=\s*(\d+)", src):
+        cname, val = m.group(1), int(m.group(2))
+        py = cname[4:] if cname.startswith("ZKE_D_") else cname
+        if hasattr(A, py):
+            assert getattr(A, py) == val, cname
+
+
+def test_no_cpu_fallback_without_gpu():
+    lib = engine.load_library()
+    if lib.zke_device_available():
+        pytest.skip("a GPU is visible")
+    with pytest.raises(z.EngineError):
+        z.Engine()
+    h = C.c_void_p()
+    assert lib.zke_engine_create(None, C.byref(h)) < 0 and not h.value
+
+
+def test_packed_batch_layout():
+    e1 = A.Email("a.com", b"raw-one", A.PublicKey(b"k1"))
+    e2 = A.Email("bb.org", b"raw-2", A.PublicKey(b"key2", "ed25519"), [A.ExternalInput("n", None)])
+    p = A.PackedBatch([e1, e2], [3], [4, 5], [[["x"], ["y", "zz"], []], [[], ["q"], ["r"]]], with_regex=True)
+    assert list(p.raw_off) == [0, 7, 12] and bytes(p.raw_blob[:12]) == b"raw-oneraw-2"
+    assert list(p.domain_off) == [0, 5, 11] and list(p.key_off) == [0, 2, 6]
+    assert list(p.key_type) == [A.KEY_RSA, A.KEY_ED25519] and list(p.ext_null) == [0, 1]
+    assert list(p.cap_off) == [0, 1, 3, 3, 3, 4, 5] and list(p.cap_str_off) == [0, 1, 2, 4, 5, 6]
+    assert p.c.n == 2 and p.c.with_regex == 1 and p.c.n_header_parts == 1 and p.c.n_body_parts == 2

@@ -1,0 +1,66 @@
+"""CPU (-m "not gpu"): the N > 1 path with world_size 2 over gloo — byte-balanced sharding and the
+all_gather of result records.  Each rank verifies its shard with the CPU oracle (the GPU engine is
+not available here); the gathered records must equal the single-process result in batch order."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+from zkemail_rs_amd import distributed as D
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np, torch, torch.distributed as dist
+import oracle_lib
+from zkemail_rs_amd import _abi as A, synth, distributed as D
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+wl = synth.make_workload("dist", 37, 6000, seed=77, ragged=True, invalid_frac=0.2)
+sizes = [len(e.raw_email) for e in wl.emails]
+bounds = D.shard_bounds(sizes, world)
+lo, hi = bounds[rank], bounds[rank + 1]
+orc = oracle_lib.load()
+local = orc.verify_batch(A.PackedBatch(wl.emails[lo:hi])) if hi > lo else np.zeros(0, A.RESULT_DTYPE)
+allrec = D.gather_records(local, [bounds[r + 1] - bounds[r] for r in range(world)])
+full = orc.verify_batch(A.PackedBatch(wl.emails))
+assert allrec.tobytes() == full.tobytes(), "gathered records differ from the single-process batch"
+my_bytes = sum(sizes[lo:hi])
+tot = torch.tensor([my_bytes], dtype=torch.int64)
+dist.all_reduce(tot)
+assert int(tot.item()) == sum(sizes)
+assert abs(my_bytes - sum(sizes) / world) <= max(sizes)      # balanced by bytes to within one e-mail
+dist.destroy_process_group()
+print("rank", rank, "ok", hi - lo)
+"""
+
+
+def test_shard_bounds_properties():
+    rng = np.random.default_rng(4)
+    for world in (1, 2, 3, 8):
+        for n in (0, 1, 5, 100):
+            sizes = [int(x) for x in rng.integers(1, 70000, n)]
+            b = D.shard_bounds(sizes, world)
+            assert len(b) == world + 1 and b[0] == 0 and b[-1] == n and all(b[i] <= b[i + 1] for i in range(world))
+            if n >= 4 * world:
+                per = [sum(sizes[b[r]:b[r + 1]]) for r in range(world)]
+                assert max(per) - min(per) <= 2 * max(sizes)
+    assert D.shard_bounds([10] * 8, 8) == list(range(9))
+
+
+def test_two_rank_gloo_gather():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER.format(root=ROOT)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+        assert "ok" in o

@@ -67,7 +67,27 @@ def build_oracle(force: bool = False) -> str:
     return ORACLE_SO
 
 
+CPP_EXAMPLE = os.path.join(ROOT, "tests", "cpp", "mirror_test")
+
+
+def build_cpp_example(force: bool = False) -> str:
+    """The C++ host mirror (include/zkemail_core.hpp) compiled against the built library."""
+    src = os.path.join(ROOT, "tests", "cpp", "mirror_test.cpp")
+    deps = [src, os.path.join(ROOT, "include", "zkemail_core.hpp"), os.path.join(ROOT, "include", "zkemail_amd.h"), ENGINE_SO]
+    if not force and not _newer(CPP_EXAMPLE, deps):
+        return CPP_EXAMPLE
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), src, "-o", CPP_EXAMPLE,
+           "-L", PKG, "-lzkemail_amd", "-L", "/opt/rocm/lib", "-lamdhip64",
+           "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("g++ failed building tests/cpp/mirror_test")
+    return CPP_EXAMPLE
+
+
 if __name__ == "__main__":
     force = "--force" in sys.argv
     print(build_oracle(force))
     print(build_engine(force, verbose="-v" in sys.argv))
+    print(build_cpp_example(force))
