@@ -92,7 +92,7 @@ enum {
   ZKE_D_U_SIG_B_REPEATED     = 65  /* the raw b= value occurs more than once in its header (reference removes every occurrence) */
 };
 
-#define ZKE_MAX_HEADERS 512u   /* header fields per email the device parser tables hold */
+#define ZKE_MAX_HEADERS 256u   /* header fields per email the device parser tables hold */
 #define ZKE_MAX_TAGS    32u    /* tag-specs per DKIM-Signature */
 #define ZKE_MAX_TAGBUF  2048u  /* bytes of FWS-stripped tag values per DKIM-Signature */
 #define ZKE_MAX_RSA_BYTES 512u /* RSA-4096, the rsa crate's ceiling (rsa 0.9.6 RsaPublicKey::MAX_SIZE) */
@@ -176,7 +176,9 @@ typedef struct zke_options {
   /* reserved[0]: max signature rounds in host mode (default 4; rounds beyond the first run only while some
    *              e-mail's earlier same-domain signature failed and a later one exists).
    * reserved[1]: signature rounds in device mode (default 1; fixed, nothing is read back).  An e-mail that
-   *              needs more reports ZKE_UNSUPPORTED / ZKE_D_U_TOO_MANY_SIGS.  Others: 0. */
+   *              needs more reports ZKE_UNSUPPORTED / ZKE_D_U_TOO_MANY_SIGS.
+   * reserved[2]: non-zero disables hipGraph replay in device mode (eager launches every time).
+   * reserved[3]: non-zero disables the per-key Montgomery-constant cache of the RSA kernel.  Others: 0. */
   uint32_t reserved[7];
 } zke_options;
 

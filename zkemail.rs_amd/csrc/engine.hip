@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstddef>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -49,6 +50,19 @@ struct RegisteredDfa {
 
 inline uint32_t e_k(uint32_t bits) { return (bits + 7) / 8; }
 
+struct GraphKey {          // everything the captured launch sequence depends on
+  zke_batch batch; uint64_t raw_total; zke_result* out; uint32_t rounds; uint32_t n_ids; uint64_t ids_hash;
+  bool operator==(const GraphKey& o) const {
+    const zke_batch &a = batch, &b = o.batch;
+    return a.n == b.n && a.raw_blob == b.raw_blob && a.raw_off == b.raw_off && a.domain_blob == b.domain_blob &&
+           a.domain_off == b.domain_off && a.key_blob == b.key_blob && a.key_off == b.key_off && a.key_type == b.key_type &&
+           a.ext_null == b.ext_null && a.with_regex == b.with_regex && a.n_header_parts == b.n_header_parts &&
+           a.n_body_parts == b.n_body_parts && a.cap_off == b.cap_off && a.cap_str_off == b.cap_str_off &&
+           a.cap_blob == b.cap_blob && raw_total == o.raw_total && out == o.out && rounds == o.rounds && n_ids == o.n_ids &&
+           ids_hash == o.ids_hash;
+  }
+};
+
 }  // namespace
 
 struct zke_engine {
@@ -68,8 +82,15 @@ struct zke_engine {
   DevBuf in_cap_off, in_cap_str_off, in_cap_blob;
   DevBuf results, meta, rsa_jobs, sha_jobs, rsa_ok, em_dbg, scratch_off, scratch, clean, meta2, scratch2, parts;
   DevBuf misc;   // building-block entry points
+  DevBuf key_cache; // KeyCacheEntry[KEY_CACHE_SLOTS]: per-key Montgomery constants, kept across batches
   DevBuf pending; // device counter: e-mails that need another signature round
   std::vector<RegisteredDfa*> dfas;
+  // hipGraph replay of the device-mode pipeline (see zke_verify_batch_device)
+  bool use_graphs = true;
+  hipGraphExec_t graph_exec = nullptr;
+  bool graph_key_valid = false;
+  GraphKey graph_key{};
+  uint32_t debug_parse_stop = 0;    // ZKE_DEBUG_PARSE_STOP: timing experiments (results are then meaningless)
   uint32_t max_sig_rounds = 4;      // host mode: upper bound, rounds are added only while e-mails are pending
   uint32_t device_mode_rounds = 1;  // device mode: fixed (no read-back)
 };
@@ -103,14 +124,16 @@ int launch_sha(zke_engine* e, const ShaJob* jobs, uint32_t n, hipStream_t s) {
 
 constexpr int SHA_TILE = 256;
 
+// key_hash_base: &results[0].public_key_hash (same stride as hash_base) or nullptr = no key cache
 int launch_rsa(zke_engine* e, const RsaJob* jobs, uint32_t n, const uint8_t* hash_base, size_t hash_stride,
-               uint32_t* ok, uint8_t* em, hipStream_t s, bool any_big) {
+               uint32_t* ok, uint8_t* em, hipStream_t s, bool any_big, const uint8_t* key_hash_base) {
   if (n == 0) return 0;
   const uint32_t grid = (n + 3) / 4;
-  hipLaunchKernelGGL(rsa_verify_kernel<1>, dim3(grid), dim3(256), 0, s, jobs, n, hash_base, hash_stride, ok, em, 2048);
+  KeyCacheEntry* cache = key_hash_base ? e->key_cache.as<KeyCacheEntry>() : nullptr;
+  hipLaunchKernelGGL(rsa_verify_kernel<1>, dim3(grid), dim3(256), 0, s, jobs, n, hash_base, hash_stride, ok, em, cache, key_hash_base);
   HIPCHK(e, hipGetLastError());
   if (any_big) {
-    hipLaunchKernelGGL(rsa_verify_kernel<2>, dim3(grid), dim3(256), 0, s, jobs, n, hash_base, hash_stride, ok, em, 4096);
+    hipLaunchKernelGGL(rsa_verify_kernel<2>, dim3(grid), dim3(256), 0, s, jobs, n, hash_base, hash_stride, ok, em, cache, key_hash_base);
     HIPCHK(e, hipGetLastError());
   }
   return 0;
@@ -142,8 +165,17 @@ int zke_engine_create(const zke_options* opt, zke_engine** out) {
   if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return ZKE_E_DEVICE; }
   for (auto& ev : e->ev) if (hipEventCreate(&ev) != hipSuccess) { delete e; return ZKE_E_DEVICE; }
   for (auto& ev : e->ev_h2d) if (hipEventCreate(&ev) != hipSuccess) { delete e; return ZKE_E_DEVICE; }
+  if (!(opt && opt->reserved[3])) {      // reserved[3] != 0: no per-key cache (R^2 mod n recomputed per signature)
+    if (e->key_cache.ensure((size_t)KEY_CACHE_SLOTS * sizeof(KeyCacheEntry)) ||
+        hipMemset(e->key_cache.p, 0, (size_t)KEY_CACHE_SLOTS * sizeof(KeyCacheEntry)) != hipSuccess) {
+      zke_engine_destroy(e);
+      return ZKE_E_NOMEM;
+    }
+  }
   if (opt && opt->reserved[0]) e->max_sig_rounds = std::min<uint32_t>(opt->reserved[0], 8);
   if (opt && opt->reserved[1]) e->device_mode_rounds = std::min<uint32_t>(opt->reserved[1], 8);
+  if (const char* ds = getenv("ZKE_DEBUG_PARSE_STOP")) e->debug_parse_stop = (uint32_t)atoi(ds);
+  if (opt && opt->reserved[2]) e->use_graphs = false;          // reserved[2] != 0: always launch eagerly
   *out = e;
   return 0;
 }
@@ -155,8 +187,9 @@ void zke_engine_destroy(zke_engine* e) {
   DevBuf* bufs[] = {&e->in_raw, &e->in_raw_off, &e->in_dom, &e->in_dom_off, &e->in_key, &e->in_key_off, &e->in_ktype,
                     &e->in_extnull, &e->in_cap_off, &e->in_cap_str_off, &e->in_cap_blob, &e->results, &e->meta,
                     &e->rsa_jobs, &e->sha_jobs, &e->rsa_ok, &e->em_dbg, &e->scratch_off, &e->scratch, &e->clean,
-                    &e->meta2, &e->misc, &e->scratch2, &e->parts, &e->pending};
+                    &e->meta2, &e->misc, &e->scratch2, &e->parts, &e->pending, &e->key_cache};
   for (auto* b : bufs) b->release();
+  if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
   for (auto* d : e->dfas) { d->blob.release(); d->dev.release(); delete d; }
   for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : e->ev_h2d) if (ev) (void)hipEventDestroy(ev);
@@ -264,7 +297,7 @@ int zke_rsa_modexp_batch(zke_engine* e, const uint8_t* sig, const uint8_t* mod, 
   hipError_t he = hipMemcpyAsync(dj.p, jobs.data(), jobs.size() * sizeof(RsaJob), hipMemcpyHostToDevice, e->stream);
   if (he == hipSuccess) he = hipMemsetAsync(dh.p, 0, (size_t)n * 32, e->stream);
   if (he == hipSuccess) he = hipMemsetAsync(dem.p, 0, (size_t)n * 512, e->stream);
-  if (he == hipSuccess) r = launch_rsa(e, dj.as<RsaJob>(), n, dh.as<uint8_t>(), 32, dok.as<uint32_t>(), dem.as<uint8_t>(), e->stream, any_big);
+  if (he == hipSuccess) r = launch_rsa(e, dj.as<RsaJob>(), n, dh.as<uint8_t>(), 32, dok.as<uint32_t>(), dem.as<uint8_t>(), e->stream, any_big, nullptr);
   std::vector<uint8_t> emh((size_t)n * 512);
   if (he == hipSuccess && r == 0) he = hipMemcpyAsync(emh.data(), dem.p, emh.size(), hipMemcpyDeviceToHost, e->stream);
   hipError_t hs = hipStreamSynchronize(e->stream);

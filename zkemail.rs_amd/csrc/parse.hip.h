@@ -81,16 +81,28 @@ struct BatchDev {
   const EmailMeta* meta_verify; // mode 1 only: the verify pass's meta
 };
 constexpr uint32_t PRE_SLACK = 1024;
+constexpr uint32_t PARSE_STAGE_BYTES = 4096;   // header blocks beyond this are read from HBM past the staged part
 
 // ------------------------------------------------------------------ byte strings and windows
 struct Str {                  // logical string over global memory with one optional excision
   const uint8_t* base;
   uint32_t len;               // logical length
   uint32_t cut, skip;         // logical index >= cut reads base[index + skip]
+  const uint8_t* lds;         // LDS copy of base[0 .. lds_len) (the staged head of the e-mail), or nullptr
+  uint32_t lds_len;
 };
-__device__ __forceinline__ Str mkstr(const uint8_t* b, uint32_t len) { return Str{b, len, NONE, 0}; }
+__device__ __forceinline__ Str mkstr(const uint8_t* b, uint32_t len) { return Str{b, len, NONE, 0, nullptr, 0}; }
+// s[a, b) as a string of its own (keeps the LDS window)
+__device__ __forceinline__ Str substr(const Str& s, uint32_t a, uint32_t b) {
+  Str r{s.base + a, b - a, NONE, 0, nullptr, 0};
+  if (s.lds && a < s.lds_len) { r.lds = s.lds + a; r.lds_len = s.lds_len - a; }
+  return r;
+}
 __device__ __forceinline__ uint32_t ldb(const Str& s, uint32_t l) {
-  return l < s.len ? (uint32_t)s.base[l + (l >= s.cut ? s.skip : 0u)] : OOB;
+  if (l >= s.len) return OOB;
+  const uint32_t phys = l + (l >= s.cut ? s.skip : 0u);
+  const uint8_t* p = phys < s.lds_len ? s.lds + phys : s.base + phys;     // one flat load either way
+  return (uint32_t)*p;
 }
 struct Win { uint32_t wpos; uint32_t c; };   // c = byte at logical wpos + lane (OOB beyond the end)
 
@@ -227,6 +239,7 @@ struct ParseLds {
   uint32_t hdr[4 * ZKE_MAX_HEADERS];   // key_start, key_end, val_start, val_end
   uint32_t tag[TG_N][4];               // raw_s, raw_e, val_off, val_len (last occurrence wins, as IndexMap::insert)
   uint8_t tagbuf[ZKE_MAX_TAGBUF];      // FWS-stripped tag values
+  __attribute__((aligned(16))) uint8_t stage[PARSE_STAGE_BYTES];   // head of the e-mail (header block), copied in 16-byte lanes
 };
 
 // strip FWS from v[rs,re) into tagbuf at *tb; returns false on overflow
@@ -537,7 +550,7 @@ __device__ __forceinline__ bool same_bytes(const Str& v, uint32_t p, uint32_t a,
 // ------------------------------------------------------------------ the parse kernel
 // mode 0: verify_email_with_key scan (round r picks the r-th same-domain candidate)
 // mode 1: canonicalize_signed_email (first DKIM-Signature header, no domain filter; core/src/circuits.rs:34-35)
-struct ParseArgs { BatchDev b; uint32_t round; uint32_t mode; };
+struct ParseArgs { BatchDev b; uint32_t round; uint32_t mode; uint32_t debug_stop; };   // debug_stop: timing experiments only (0 = off)
 
 __device__ const uint8_t DKIM_NAME[14] = {'D', 'K', 'I', 'M', '-', 'S', 'i', 'g', 'n', 'a', 't', 'u', 'r', 'e'};
 
@@ -560,7 +573,19 @@ __global__ __launch_bounds__(64) void parse_kernel(ParseArgs A) {
   }
 
   const uint64_t r0 = B.raw_off[i], r1 = B.raw_off[i + 1];
-  const Str raw = mkstr(B.raw + r0, (uint32_t)(r1 - r0));
+  Str raw = mkstr(B.raw + r0, (uint32_t)(r1 - r0));
+  {
+    // Stage the head of the e-mail in LDS with 16-byte lane-contiguous loads: every later scan of the header
+    // block (split, tag lists, canonicalisation) then costs LDS latency instead of a dependent L2 round trip.
+    const uint32_t want = raw.len < PARSE_STAGE_BYTES ? raw.len : PARSE_STAGE_BYTES;
+    const uint32_t full = want & ~15u;
+    for (uint32_t o = lane * 16; o < full; o += 64 * 16) *(uint4*)(L.stage + o) = *(const uint4_unaligned*)(raw.base + o);
+    for (uint32_t o = full + lane; o < want; o += 64) L.stage[o] = raw.base[o];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    raw.lds = L.stage; raw.lds_len = want;
+  }
+  if (A.debug_stop == 1) return;
   const Str dom = mkstr(B.dom + B.dom_off[i], (uint32_t)(B.dom_off[i + 1] - B.dom_off[i]));
   const Str key = mkstr(B.key + B.key_off[i], (uint32_t)(B.key_off[i + 1] - B.key_off[i]));
   uint8_t* regA = B.scratch + B.scratch_off[i];
@@ -609,7 +634,9 @@ __global__ __launch_bounds__(64) void parse_kernel(ParseArgs A) {
     finish(perr == ZKE_D_U_TOO_MANY_HEADERS ? ZKE_UNSUPPORTED : ZKE_PARSE_FAIL, perr);
     return;
   }
+  if (A.debug_stop == 2) return;
   const uint32_t body_off = find_body(raw);
+  if (A.debug_stop == 3) return;
   if (lane == 0) {
     if (A.mode == 0) { R->n_headers = nh; R->body_offset = body_off; }
     M->n_headers = nh; M->body_off = body_off; M->body_len = raw.len - body_off;
@@ -632,6 +659,7 @@ __global__ __launch_bounds__(64) void parse_kernel(ParseArgs A) {
     sha_job(3, key.base, key.len, R->public_key_hash);
   }
 
+  if (A.debug_stop == 4) return;
   // ---- scan the DKIM-Signature headers in file order
   uint32_t sig_ix = 0, cand_count = 0, last_touched = 0, unsupported = 0;
   uint32_t err_all = 0;        // last non-candidate error anywhere
@@ -644,7 +672,7 @@ __global__ __launch_bounds__(64) void parse_kernel(ParseArgs A) {
     const uint32_t this_ix = sig_ix++;
     if (first_sig_hdr == NONE) first_sig_hdr = hx;
     if (A.mode == 1 && hx != first_sig_hdr) break;
-    const Str v = mkstr(raw.base + vs, ve - vs);
+    const Str v = substr(raw, vs, ve);
     auto note_err = [&](uint32_t e) { err_all = e; if (have_cand) err_after = e; last_touched = this_ix; };
     // from_utf8_lossy would rewrite invalid UTF-8: any byte >= 0x80 is reported, never guessed
     {
@@ -657,6 +685,7 @@ __global__ __launch_bounds__(64) void parse_kernel(ParseArgs A) {
     }
     uint32_t present;
     const uint32_t verr = validate_sig(L, v, present);
+    if (A.debug_stop == 5) return;
     if (verr == ZKE_D_U_TOO_MANY_TAGS || verr == ZKE_D_U_SIG_TOO_LONG) {
       unsupported = verr; last_touched = this_ix;
       if (A.mode == 1) { finish(ZKE_UNSUPPORTED, verr); return; }
@@ -750,6 +779,7 @@ __global__ __launch_bounds__(64) void parse_kernel(ParseArgs A) {
         continue;
       }
     }
+    if (A.debug_stop == 6) return;
     // ---- header-hash preimage (cfdkim hash::compute_headers_hash)
     Out out{regA, 0, capA, false};
     const bool hrel = (flags & ZKE_F_HDR_RELAXED) != 0;
@@ -793,7 +823,7 @@ __global__ __launch_bounds__(64) void parse_kernel(ParseArgs A) {
         }
         if (found != NONE) {
           const uint32_t* sp = L.hdr + 4 * found;
-          emit_header(out, mkstr(raw.base + sp[0], sp[1] - sp[0]), mkstr(raw.base + sp[2], sp[3] - sp[2]), hrel, true);
+          emit_header(out, substr(raw, sp[0], sp[1]), substr(raw, sp[2], sp[3]), hrel, true);
         }
         st = e + 1;
       }

@@ -39,6 +39,21 @@ enum : uint32_t {
   RSA_F_ACTIVE = 1,             // run the modexp
 };
 
+// Per-key Montgomery constants, cached across e-mails and batches.  An entry is claimed once
+// (state 0 -> 1 by atomicCAS), written, published (state 2) and never modified again, so readers need
+// no lock: state == 2 + acquire, then compare the full SHA-256 of the key bytes.  A key whose slot is
+// owned by another key is simply not cached.
+struct KeyCacheEntry {
+  uint32_t state;               // 0 empty, 1 being filled, 2 valid
+  uint32_t ninv;                // -n^-1 mod 2^32
+  uint32_t bits;                // modulus bit length
+  uint32_t pad;
+  uint32_t hash[8];             // SHA-256 of the DER key (zke_result.public_key_hash)
+  uint32_t rr[128];             // R^2 mod n, limb q*64+lane
+};
+static_assert(sizeof(KeyCacheEntry) == 560, "KeyCacheEntry layout");
+constexpr uint32_t KEY_CACHE_SLOTS = 4096;
+
 // ---- cross-lane helpers -------------------------------------------------------------
 // value of lane+1 (lane 63 gets 0): v_mov_b32_dpp wave_shl:1 bound_ctrl:0
 __device__ __forceinline__ uint32_t lane_up(uint32_t x) {
@@ -196,7 +211,7 @@ template <int NL>
 __global__ __launch_bounds__(256) void rsa_verify_kernel(const RsaJob* __restrict__ jobs, uint32_t n,
                                                          const uint8_t* __restrict__ hash_base, size_t hash_stride,
                                                          uint32_t* __restrict__ ok_out, uint8_t* __restrict__ em_out,
-                                                         int max_bits_this_launch) {
+                                                         KeyCacheEntry* cache, const uint8_t* __restrict__ key_hash_base) {
   const int lane = threadIdx.x & 63;
   const uint32_t job = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (job >= n) return;
@@ -204,7 +219,6 @@ __global__ __launch_bounds__(256) void rsa_verify_kernel(const RsaJob* __restric
   const uint32_t flags = J->flags, k = J->k, bits = J->bits;
   // this launch handles moduli in (max_bits/2, max_bits]; others belong to the sibling launch
   const bool mine = (NL == 1) ? (bits <= 2048) : (bits > 2048);
-  (void)max_bits_this_launch;
   if (!mine) return;
 
   Big<NL> nn, s;
@@ -222,30 +236,65 @@ __global__ __launch_bounds__(256) void rsa_verify_kernel(const RsaJob* __restric
 #pragma unroll
   for (int q = 0; q < NL; q++) em.v[q] = 0;
   if ((flags & RSA_F_ACTIVE) && odd && lenok && bits >= 2 && !big_ge<NL>(s, nn)) {
-    // ninv = -n^-1 mod 2^32 (Newton; n odd)
-    uint32_t n0 = __builtin_amdgcn_readfirstlane(nn.v[0]);
-    uint32_t x = n0;
+    Big<NL> rr;
+    uint32_t ninv = 0;
+    bool hit = false;
+    KeyCacheEntry* E = nullptr;
+    const uint32_t* kh = nullptr;
+    if (cache) {
+      kh = (const uint32_t*)(key_hash_base + (size_t)job * hash_stride);
+      E = cache + (kh[0] % KEY_CACHE_SLOTS);
+      if (__hip_atomic_load(&E->state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2u) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const bool same = (lane < 8) ? (E->hash[lane] == kh[lane]) : true;
+        if (ballot64(!same) == 0 && E->bits == bits) {
 #pragma unroll
-    for (int i = 0; i < 5; i++) x *= 2 - n0 * x;
-    const uint32_t ninv = 0u - x;
-    // one = R mod n.  2^bits - n, then double (container_bits - bits) times.
-    Big<NL> one;
-    {
-      Big<NL> pw;                                            // 2^bits mod 2^container (0 when bits == container)
-#pragma unroll
-      for (int q = 0; q < NL; q++) {
-        const uint32_t limb = q * 64 + lane;
-        pw.v[q] = (bits < 2048u * NL && (bits >> 5) == limb) ? (1u << (bits & 31)) : 0u;
+          for (int q = 0; q < NL; q++) rr.v[q] = E->rr[q * 64 + lane];
+          ninv = E->ninv;
+          hit = true;
+        }
       }
-      big_sub<NL>(one, pw, nn, lane);                        // 2^bits - n  (mod 2^container): in [1, n)
-      for (uint32_t i = bits; i < 2048u * NL; i++) mod_double<NL>(one, nn, lane);
     }
-    Big<NL> rr = one;
-    mod_double<NL>(rr, nn, lane);                            // 2R mod n
-    // (2R)^(2^t) in the Montgomery domain = 2^(2^t) R; t = log2(container bits) -> R*R = R^2 mod n
-    constexpr int T = (NL == 1) ? 11 : 12;
+    if (!hit) {
+      // ninv = -n^-1 mod 2^32 (Newton; n odd)
+      uint32_t n0 = __builtin_amdgcn_readfirstlane(nn.v[0]);
+      uint32_t x = n0;
+#pragma unroll
+      for (int i = 0; i < 5; i++) x *= 2 - n0 * x;
+      ninv = 0u - x;
+      // one = R mod n.  2^bits - n, then double (container_bits - bits) times.
+      Big<NL> one;
+      {
+        Big<NL> pw;                                            // 2^bits mod 2^container (0 when bits == container)
+#pragma unroll
+        for (int q = 0; q < NL; q++) {
+          const uint32_t limb = q * 64 + lane;
+          pw.v[q] = (bits < 2048u * NL && (bits >> 5) == limb) ? (1u << (bits & 31)) : 0u;
+        }
+        big_sub<NL>(one, pw, nn, lane);                        // 2^bits - n  (mod 2^container): in [1, n)
+        for (uint32_t i = bits; i < 2048u * NL; i++) mod_double<NL>(one, nn, lane);
+      }
+      rr = one;
+      mod_double<NL>(rr, nn, lane);                            // 2R mod n
+      // (2R)^(2^t) in the Montgomery domain = 2^(2^t) R; t = log2(container bits) -> R*R = R^2 mod n
+      constexpr int T = (NL == 1) ? 11 : 12;
 #pragma unroll 1
-    for (int i = 0; i < T; i++) mont_mul<NL>(rr, rr, rr, nn, ninv, lane);
+      for (int i = 0; i < T; i++) mont_mul<NL>(rr, rr, rr, nn, ninv, lane);
+      if (cache) {
+        uint32_t won = 0;
+        if (lane == 0) won = atomicCAS(&E->state, 0u, 1u) == 0u ? 1u : 0u;
+        won = __builtin_amdgcn_readfirstlane(won);
+        if (won) {
+          if (lane < 8) E->hash[lane] = kh[lane];
+          if (lane == 0) { E->ninv = ninv; E->bits = bits; }
+#pragma unroll
+          for (int q = 0; q < NL; q++) E->rr[q * 64 + lane] = rr.v[q];
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (lane == 0) __hip_atomic_store(&E->state, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
     Big<NL> xm;
     mont_mul<NL>(xm, s, rr, nn, ninv, lane);                 // s in Montgomery form
     Big<NL> acc = xm;
