@@ -196,6 +196,36 @@ def main():
                 "and a 1024-message launch is bounded by the 65-block dependency chain of one message; see DESIGN.md",
     }
 
+    # ---- the same SHA-256 kernel with enough independent messages to fill the chip (kernel capability, not the
+    # workload's roofline): 2^18 messages x 4 KiB resident in HBM, HIP-event timed on the launch stream
+    sha_sat = None
+    if rank == 0 and world == 1:
+        nm, ml = 1 << 18, 4096
+        blob = torch.randint(0, 256, (nm * ml + 64,), dtype=torch.uint8, device=dev)
+        off = (torch.arange(nm + 1, dtype=torch.int64, device=dev) * ml)
+        dig = torch.zeros(nm * 32, dtype=torch.uint8, device=dev)
+        cur = streams[0]          # a real (non-null) HIP stream: the engine launches on the handle it is given
+        torch.cuda.synchronize()
+        lib = eng.lib
+        for _ in range(2):
+            lib.zke_sha256_batch_device(eng.h, blob.data_ptr(), off.data_ptr(), nm, dig.data_ptr(), cur.cuda_stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 5
+        e0.record(cur)
+        for _ in range(reps):
+            lib.zke_sha256_batch_device(eng.h, blob.data_ptr(), off.data_ptr(), nm, dig.data_ptr(), cur.cuda_stream)
+        e1.record(cur)
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        import hashlib
+        for i in (0, nm // 2, nm - 1):
+            assert bytes(dig[32 * i:32 * i + 32].cpu().numpy()) == hashlib.sha256(bytes(blob[i * ml:(i + 1) * ml].cpu().numpy())).digest()
+        gbs = (nm * (ml + 32)) / (ms * 1e-3) / 1e9
+        sha_sat = {"messages": nm, "message_bytes": ml, "ms_per_launch": round(ms, 3), "achieved_GBps": round(gbs, 1),
+                   "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4), "valu_ceiling_GBps": 3500,
+                   "note": "includes the small job-list kernel; ceiling = 78.6 T lane-instr/s / 22 instr per byte"}
+        del blob, off, dig
+
     out = {
         "metric": "emails verified/sec (witness gen)", "value": round(emails_per_s, 1), "unit": "emails/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
@@ -206,6 +236,7 @@ def main():
                    "inputs": "HBM-resident raw e-mails", "batches_in_flight": S, "collective": "all_gather of 192-B result records (RCCL)" if world > 1 else "none"},
         "roofline": roof,
         "kernels_us": {k: round(v, 2) for k, v in kern.items()},
+        "sha256_saturated": sha_sat,
         "workload_gen_s": round(gen_s, 2),
     }
 

@@ -49,6 +49,7 @@ struct RegisteredDfa {
 };
 
 inline uint32_t e_k(uint32_t bits) { return (bits + 7) / 8; }
+constexpr int SHA_TILE = 128;
 
 struct GraphKey {          // everything the captured launch sequence depends on
   zke_batch batch; uint64_t raw_total; zke_result* out; uint32_t rounds; uint32_t n_ids; uint64_t ids_hash;
@@ -90,6 +91,7 @@ struct zke_engine {
   hipGraphExec_t graph_exec = nullptr;
   bool graph_key_valid = false;
   GraphKey graph_key{};
+  int sha_tile = SHA_TILE;
   uint32_t debug_parse_stop = 0;    // ZKE_DEBUG_PARSE_STOP: timing experiments (results are then meaningless)
   uint32_t max_sig_rounds = 4;      // host mode: upper bound, rounds are added only while e-mails are pending
   uint32_t device_mode_rounds = 1;  // device mode: fixed (no read-back)
@@ -122,7 +124,15 @@ int launch_sha(zke_engine* e, const ShaJob* jobs, uint32_t n, hipStream_t s) {
   return 0;
 }
 
-constexpr int SHA_TILE = 256;
+// tile size is a tuning knob (LDS per wave = 64 * (T + 16) bytes sets the occupancy); ZKE_SHA_TILE overrides for experiments
+int launch_sha_any(zke_engine* e, const ShaJob* jobs, uint32_t n, hipStream_t s) {
+  switch (e->sha_tile) {
+    case 64: return launch_sha<64>(e, jobs, n, s);
+    case 256: return launch_sha<256>(e, jobs, n, s);
+    case 512: return launch_sha<512>(e, jobs, n, s);
+    default: return launch_sha<SHA_TILE>(e, jobs, n, s);
+  }
+}
 
 // key_hash_base: &results[0].public_key_hash (same stride as hash_base) or nullptr = no key cache
 int launch_rsa(zke_engine* e, const RsaJob* jobs, uint32_t n, const uint8_t* hash_base, size_t hash_stride,
@@ -174,6 +184,8 @@ int zke_engine_create(const zke_options* opt, zke_engine** out) {
   }
   if (opt && opt->reserved[0]) e->max_sig_rounds = std::min<uint32_t>(opt->reserved[0], 8);
   if (opt && opt->reserved[1]) e->device_mode_rounds = std::min<uint32_t>(opt->reserved[1], 8);
+  if (getenv("ZKE_NO_GRAPHS")) e->use_graphs = false;
+  if (const char* st = getenv("ZKE_SHA_TILE")) e->sha_tile = atoi(st);
   if (const char* ds = getenv("ZKE_DEBUG_PARSE_STOP")) e->debug_parse_stop = (uint32_t)atoi(ds);
   if (opt && opt->reserved[2]) e->use_graphs = false;          // reserved[2] != 0: always launch eagerly
   *out = e;
@@ -232,7 +244,7 @@ int zke_sha256_batch_device(zke_engine* e, const uint8_t* blob_dev, const uint64
   hipLaunchKernelGGL(sha_jobs_from_csr_kernel, dim3((n + 255) / 256), dim3(256), 0, s, blob_dev, off_dev, n, digests_dev,
                      e->misc.as<ShaJob>());
   HIPCHK(e, hipGetLastError());
-  return launch_sha<SHA_TILE>(e, e->misc.as<ShaJob>(), n, s);
+  return launch_sha_any(e, e->misc.as<ShaJob>(), n, s);
 }
 
 int zke_sha256_batch(zke_engine* e, const uint8_t* blob, const uint64_t* off, uint32_t n, uint8_t* digests) {

@@ -86,7 +86,7 @@ int run_device_pipeline(zke_engine* e, const zke_batch* in, uint64_t raw_total, 
     CanonArgs ca{B, 0};
     hipLaunchKernelGGL(canon_body_kernel, dim3(n), dim3(64), 0, s, ca);
     if (round == 0) tm.mark();
-    if ((r = launch_sha<SHA_TILE>(e, B.sha, 4 * n_pad, s))) return r;
+    if ((r = launch_sha_any(e, B.sha, 4 * n_pad, s))) return r;
     if (round == 0) tm.mark();
     if ((r = launch_rsa(e, B.rsa, n, reinterpret_cast<const uint8_t*>(out_dev) + offsetof(zke_result, header_hash),
                         sizeof(zke_result), e->rsa_ok.as<uint32_t>(), want_em ? e->em_dbg.as<uint8_t>() : nullptr, s, true,

@@ -105,10 +105,14 @@ __global__ __launch_bounds__(256) void sha256_batch_kernel(const ShaJob* __restr
   uint32_t st[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
   uint8_t* my_row = slab + lane * ROW;
 
-  for (uint32_t blk0 = 0; blk0 < max_nblk; blk0 += T / 64) {
+  // Software pipeline: the global loads of tile t+1 are issued into registers BEFORE tile t is compressed and
+  // land in LDS after it, so a wave's HBM latency hides under its own ~LPR/4 x 1.4k VALU of compression.
+  uint4 stage[LPR];
+  uint32_t live = 0;                       // bit g: stage[g] holds a row chunk that must be written to LDS
+  auto fetch = [&](uint32_t blk0) {
     const uint32_t tile_off = blk0 * 64;
-    // ---- cooperative fill: RPI rows per instruction, 16 B per lane
-#pragma unroll 4
+    live = 0;
+#pragma unroll
     for (int g = 0; g < LPR; g++) {
       const int row = g * RPI + lane / LPR;
       const int chunk = lane % LPR;
@@ -116,8 +120,9 @@ __global__ __launch_bounds__(256) void sha256_batch_kernel(const ShaJob* __restr
       const uint32_t rlen = *(const uint32_t*)(desc + row * 16 + 8);
       const uint32_t rnblk = *(const uint32_t*)(desc + row * 16 + 12);
       const uint32_t off = tile_off + chunk * 16;
+      uint4 v = make_uint4(0, 0, 0, 0);
       if (blk0 < rnblk) {                      // rows that are already finished are skipped
-        uint4 v = make_uint4(0, 0, 0, 0);
+        live |= 1u << g;
         if (off + 16 <= rlen) {
           v = *(const uint4_unaligned*)(rsrc + off);
         } else if (off < rlen) {               // last partial chunk of the message: byte loads, never past the end
@@ -126,8 +131,17 @@ __global__ __launch_bounds__(256) void sha256_batch_kernel(const ShaJob* __restr
           for (uint32_t b = 0; b < rem; b++) t[b >> 2] |= (uint32_t)p[b] << (8 * (b & 3));
           v = make_uint4(t[0], t[1], t[2], t[3]);
         }
-        *(uint4*)(slab + row * ROW + chunk * 16) = v;
       }
+      stage[g] = v;
+    }
+  };
+  auto commit = [&](uint32_t blk0) {           // registers -> LDS slab, then the padding of this tile
+    const uint32_t tile_off = blk0 * 64;
+#pragma unroll
+    for (int g = 0; g < LPR; g++) {
+      const int row = g * RPI + lane / LPR;
+      const int chunk = lane % LPR;
+      if (live & (1u << g)) *(uint4*)(slab + row * ROW + chunk * 16) = stage[g];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -144,6 +158,13 @@ __global__ __launch_bounds__(256) void sha256_batch_kernel(const ShaJob* __restr
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+  };
+
+  if (max_nblk) { fetch(0); commit(0); }
+  for (uint32_t blk0 = 0; blk0 < max_nblk; blk0 += T / 64) {
+    const uint32_t next = blk0 + T / 64;
+    const bool more = next < max_nblk;
+    if (more) fetch(next);                     // in flight during the compression below
     // ---- compress: one message per lane
 #pragma unroll 1
     for (int b = 0; b < T / 64; b++) {
@@ -160,6 +181,7 @@ __global__ __launch_bounds__(256) void sha256_batch_kernel(const ShaJob* __restr
       }
     }
     __builtin_amdgcn_wave_barrier();
+    if (more) commit(next);
   }
   if (m < n && my_dst) {
     uint32_t* out = (uint32_t*)my_dst;      // digests are 4-byte aligned (result records / engine buffers)
