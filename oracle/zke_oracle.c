@@ -470,6 +470,7 @@ static long parse_tag_spec(const uint8_t* s, size_t n, size_t pos, taglist_t* tl
   for (size_t i = rs; i < re; i++)
     if (!is_fws(s[i])) tl->tagbuf[tl->tagbuf_len++] = s[i];
   t->val_len = (uint32_t)(tl->tagbuf_len - t->val_off);
+  if (tl->tagbuf_len > ZKE_MAX_TAGBUF) { *overflow = 2; return (long)p; }   /* engine limit, mirrored so parity is defined */
   return (long)p;
 }
 /* tag-list = tag-spec *( ";" tag-spec ) [ ";" ]; trailing garbage is ignored (nom remainder dropped) */
@@ -477,7 +478,7 @@ static int parse_tag_list(const uint8_t* s, size_t n, taglist_t* tl, int* overfl
   tl->ntags = 0; tl->tagbuf_len = 0;
   long p = parse_tag_spec(s, n, 0, tl, overflow);
   if (p < 0) return -1;
-  while ((size_t)p < n && s[p] == ';') {
+  while (!*overflow && (size_t)p < n && s[p] == ';') {
     long q = parse_tag_spec(s, n, (size_t)p + 1, tl, overflow);
     if (q < 0) break;
     p = q;
@@ -503,7 +504,8 @@ static int tag_eq(const taglist_t* tl, const tag_t* t, const char* lit) {
 static int validate_header(const uint8_t* s, size_t n, taglist_t* tl) {
   int overflow = 0;
   if (parse_tag_list(s, n, tl, &overflow)) return ZKE_D_SIG_SYNTAX;
-  if (overflow) return ZKE_D_U_TOO_MANY_TAGS;
+  if (overflow == 1) return ZKE_D_U_TOO_MANY_TAGS;
+  if (overflow == 2) return ZKE_D_U_SIG_TOO_LONG;
   static const char* req[] = {"v", "a", "b", "bh", "d", "h", "s"};
   for (int i = 0; i < 7; i++)
     if (!get_tag(tl, s, req[i])) return ZKE_D_MISSING_TAG;
@@ -1158,7 +1160,7 @@ static void verify_one(const zke_batch* in, uint32_t i, zke_result* out, zke_deb
     const uint8_t* sv = raw + sp[2]; size_t svl = sp[3] - sp[2];
     if (value_has_non_ascii(sv, svl)) { unsupported = ZKE_D_U_SIG_NON_ASCII; out->sig_index = this_ix; continue; }
     int v = validate_header(sv, svl, &tl);
-    if (v == ZKE_D_U_TOO_MANY_TAGS) { unsupported = v; out->sig_index = this_ix; continue; }
+    if (v == ZKE_D_U_TOO_MANY_TAGS || v == ZKE_D_U_SIG_TOO_LONG) { unsupported = v; out->sig_index = this_ix; continue; }
     if (v) { last_err = (uint32_t)v; out->sig_index = this_ix; continue; }
     const tag_t* td = get_tag(&tl, sv, "d");
     if (!key_ieq(tl.tagbuf + td->val_off, td->val_len, dom, dom_len)) continue;
@@ -1215,7 +1217,7 @@ static void verify_one(const zke_batch* in, uint32_t i, zke_result* out, zke_deb
   if (!sv) { out->status = ZKE_CANON_FAIL; out->detail = ZKE_D_NO_SIGNATURE; return; }
   if (value_has_non_ascii(sv, svl)) { out->status = ZKE_UNSUPPORTED; out->detail = ZKE_D_U_SIG_NON_ASCII; return; }
   int v = validate_header(sv, svl, &tl);
-  if (v == ZKE_D_U_TOO_MANY_TAGS) { out->status = ZKE_UNSUPPORTED; out->detail = (uint32_t)v; return; }
+  if (v == ZKE_D_U_TOO_MANY_TAGS || v == ZKE_D_U_SIG_TOO_LONG) { out->status = ZKE_UNSUPPORTED; out->detail = (uint32_t)v; return; }
   if (v) { out->status = ZKE_CANON_FAIL; out->detail = (uint32_t)v; return; }
   v = canon_for_sig(&pm, sv, svl, &tl, &cn, NULL);
   if (v) { out->status = ZKE_CANON_FAIL; out->detail = (uint32_t)v; return; }

@@ -180,3 +180,40 @@ def _two_sigs(first_broken: bool = False) -> Case:
 
 def expected_witness(c: Case):
     return (hashlib.sha256(c.email.from_domain.encode()).digest(), hashlib.sha256(c.email.public_key.key).digest())
+
+
+def build_limit_cases() -> List[Case]:
+    """Engine limits and large inputs: the oracle mirrors the limits, so parity stays defined."""
+    cs: List[Case] = []
+    k0 = K()
+    many = [(b"X-Filler-%d" % i, b"v%d" % i) for i in range(240)]
+    cs.append(mk("pass_250_headers", many + _hdrs(30), _body(200, 30), k0))
+    too_many = [(b"X-Filler-%d" % i, b"v") for i in range(260)]
+    cs.append(mk("unsupported_300_headers", too_many + _hdrs(30), _body(200, 30), k0,
+                 status=A.ZKE_UNSUPPORTED, detail=A.D_U_TOO_MANY_HEADERS, check_inter=False))
+    # a 14 KB header block: far beyond what the front end stages in LDS
+    big = [(b"Received", (b"from relay-%d.example.net by mx.example.net with ESMTP id %08x;\r\n\tTue, 03 Oct 2026 10:00:00 +0000" % (i, i)))
+           for i in range(120)]
+    for hc in ("relaxed", "simple"):
+        cs.append(mk(f"pass_big_header_block_{hc}", big + _hdrs(31), _body(3000, 31), k0,
+                     SignSpec(header_canon=hc, signed=("from", "to", "subject", "date", "message-id", "received", "received", "received"))))
+    tags33 = "".join(f"x{i}=1; " for i in range(30))
+    cs.append(mk("unsupported_too_many_tags", _hdrs(32), _body(100, 32), k0, SignSpec(extra_tags=tags33),
+                 status=A.ZKE_UNSUPPORTED, detail=A.D_U_TOO_MANY_TAGS, check_inter=False))
+    cs.append(mk("pass_24_tags", _hdrs(32), _body(100, 32), k0, SignSpec(extra_tags="".join(f"x{i}=1; " for i in range(15)))))
+    cs.append(mk("unsupported_sig_too_long", _hdrs(33), _body(100, 33), k0, SignSpec(extra_tags="z=" + "A" * 2100 + "; "),
+                 status=A.ZKE_UNSUPPORTED, detail=A.D_U_SIG_TOO_LONG, check_inter=False))
+    cs.append(mk("pass_sig_1500_tag_bytes", _hdrs(33), _body(100, 33), k0, SignSpec(extra_tags="z=" + "A" * 900 + "; ")))
+    return cs
+
+
+def multi_signature_case(n_bad: int) -> Case:
+    """n_bad same-domain signatures over a different body (body hash fails), then the good one."""
+    k0 = K()
+    hs, body = _hdrs(40), _body(333, 40)
+    raw, inter = sign_email(hs, body, k0, SignSpec())
+    prefix = b""
+    for j in range(n_bad):
+        raw_bad, _ = sign_email(hs, _body(120 + j, 41 + j), k0, SignSpec(selector=f"old{j}"))
+        prefix += raw_bad[:raw_bad.find(b"Received:")]
+    return Case(f"pass_after_{n_bad}_failed_signatures", Email("example.com", prefix + raw, PublicKey(k0.pkcs1_der)), A.ZKE_OK, None, inter)

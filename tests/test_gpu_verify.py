@@ -124,3 +124,111 @@ def test_mutation_fuzz_parity(engine, oracle):
     assert_records_equal(got, exp, None, "fuzz")
     assert (d1.canon_header == d2.canon_header).all() and (d1.canon_body == d2.canon_body).all()
     assert len(set(int(s) for s in exp["status"])) >= 3        # the fuzz reaches several outcomes
+
+
+def test_lane_front_end_variant_parity(tmp_path):
+    """The one-e-mail-per-lane front end (csrc/front.hip.h, ZKE_LANE_PARSE=1) must produce the same records as
+    the oracle on the corpus and the fuzz set; run in a subprocess because the choice is made at engine creation."""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent(f"""
+        import sys
+        sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r})
+        import oracle_lib, cases, test_gpu_verify as t, test_gpu_regex as tr
+        import zkemail_rs_amd as z
+        from zkemail_rs_amd import synth
+        eng, orc = z.Engine(), oracle_lib.load()
+        t.test_case_corpus_parity(eng, orc)
+        t.test_mutation_fuzz_parity(eng, orc)
+        t.test_workload_parity(eng, orc, dict(n=70, body_len=20000, rsa_bits=2048, seed=7, ragged=True, invalid_frac=0.2))
+        tr.test_first_signature_canonicalisation_parity(eng, orc)
+        tr.test_regex_workload_parity(eng, orc, dict(n=96, body_len=4096, rsa_bits=4096, n_keys=8, n_header_parts=2,
+                                                    n_body_parts=2, qp_frac=0.05, fail_frac=0.3, seed=5))
+        print("lane front end ok")
+    """)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ZKE_LANE_PARSE="1"), capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "lane front end ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_limits_and_large_header_blocks_parity(engine, oracle):
+    cs = cases.build_limit_cases()
+    got, exp, d1, d2 = run_both(engine, oracle, [c.email for c in cs])
+    assert_records_equal(got, exp, [c.name for c in cs], "limits")
+    assert (d1.canon_header == d2.canon_header).all()
+    for i, c in enumerate(cs):
+        assert int(got[i]["status"]) == c.status, c.name
+        if c.detail is not None:
+            assert int(got[i]["detail"]) == c.detail, c.name
+
+
+def test_signature_rounds(engine, oracle):
+    """Host mode adds signature rounds while e-mails are pending (default up to 4): 3 failing same-domain
+    signatures then a good one verifies; 5 failing ones exceed the rounds and are reported, never guessed."""
+    cs = [cases.multi_signature_case(k) for k in (1, 2, 3)]
+    got, exp, _, _ = run_both(engine, oracle, [c.email for c in cs])
+    assert_records_equal(got, exp, [c.name for c in cs], "rounds")
+    assert (got["status"] == 0).all() and [int(x) for x in got["sig_index"]] == [1, 2, 3]
+    c5 = cases.multi_signature_case(5)
+    got5, exp5, _, _ = run_both(engine, oracle, [c5.email])
+    assert int(exp5[0]["status"]) == A.ZKE_OK                       # the reference would pass it
+    assert int(got5[0]["status"]) == A.ZKE_UNSUPPORTED and int(got5[0]["detail"]) == A.D_U_TOO_MANY_SIGS
+
+
+def test_repeated_b_value_is_reported(engine, oracle):
+    """cfdkim removes EVERY occurrence of the raw b= value from the header before hashing; the wavefront front
+    end removes the tag's own span and reports a second occurrence instead of guessing."""
+    c = [x for x in cases.build_cases() if x.name == "pass_extra_tags_unfolded"][0]
+    raw = c.email.raw_email
+    i = raw.find(b" b=") + 3
+    j = raw.find(b"\r\n", i)
+    bval = raw[i:j]
+    mutated = raw.replace(b"v=1;", b"v=1; z=" + bval + b";", 1)
+    e = A.Email(c.email.from_domain, mutated, c.email.public_key)
+    got, exp, _, _ = run_both(engine, oracle, [e])
+    assert int(exp[0]["status"]) == A.ZKE_DKIM_NOT_PASS and int(exp[0]["detail"]) == A.D_SIG_MISMATCH
+    assert int(got[0]["status"]) == A.ZKE_UNSUPPORTED and int(got[0]["detail"]) == A.D_U_SIG_B_REPEATED
+
+
+def test_device_resident_entry_matches_host_entry():
+    """zke_verify_batch_device (HBM pointers, caller's stream, repeated submissions of the same descriptor)
+    returns the records zke_verify_batch returns, for verify_email and for verify_email_with_regex.  Runs in a
+    subprocess so that torch (which owns the device buffers) initialises HIP before the engine does."""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent(f"""
+        import sys
+        sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r})
+        import numpy as np, torch
+        torch.zeros(1, device="cuda")
+        import bench, zkemail_rs_amd as z
+        from zkemail_rs_amd import _abi as A, synth
+        from test_gpu_verify import assert_records_equal
+        engine = z.Engine(0)
+        dev = torch.device("cuda", 0)
+        inputs, wl, _ = synth.make_regex_workload("dev", 150, 2048, n_header_parts=2, n_body_parts=1, qp_frac=0.05, fail_frac=0.2, seed=21)
+        for with_regex in (False, True):
+            packed = engine.pack_with_regex(inputs) if with_regex else A.PackedBatch(wl.emails)
+            host = engine.verify_batch(packed)
+            cb, keep, totals = bench.device_batch(torch, packed, dev)
+            extra = {{}}
+            if with_regex:
+                for name, arr in (("cap_off", packed.cap_off), ("cap_str_off", packed.cap_str_off), ("cap_blob", packed.cap_blob)):
+                    extra[name] = torch.from_numpy(arr.view(np.uint8).copy()).to(dev)
+                cb.with_regex = 1
+                cb.n_header_parts, cb.n_body_parts = packed.nh, packed.nb
+                cb.header_part_ids, cb.body_part_ids = packed.hdr_ids.ctypes.data, packed.body_ids.ctypes.data   # host arrays
+                cb.cap_off, cb.cap_str_off, cb.cap_blob = (extra[k].data_ptr() for k in ("cap_off", "cap_str_off", "cap_blob"))
+            out = torch.zeros(packed.n * 192, dtype=torch.uint8, device=dev)
+            st = torch.cuda.Stream()
+            for rep in range(4):
+                out.zero_()
+                torch.cuda.synchronize()
+                engine.verify_batch_device(cb, totals[0], totals[1], totals[2], out.data_ptr(), st.cuda_stream)
+                torch.cuda.synchronize()
+                rec = out.cpu().numpy().view(A.RESULT_DTYPE)
+                assert_records_equal(rec, host, None, f"device mode rep {{rep}} regex={{with_regex}}")
+        print("device entry ok")
+    """)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "device entry ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

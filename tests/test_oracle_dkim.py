@@ -115,3 +115,11 @@ def test_qp_soft_breaks(oracle):
     assert oracle.remove_qp(b"x==\r\ny") == b"x=y\0\0\0"
     assert oracle.remove_qp(b"") == b""
     assert oracle.remove_qp(b"=\r") == b"=\r"
+
+
+LIMITS = cases.build_limit_cases() + [cases.multi_signature_case(k) for k in (2, 3, 5)]
+
+
+@pytest.mark.parametrize("case", LIMITS, ids=[c.name for c in LIMITS])
+def test_oracle_limit_case(oracle, case):
+    test_oracle_case(oracle, case)

@@ -18,6 +18,7 @@
 #include "sha256.hip.h"
 #include "rsa.hip.h"
 #include "parse.hip.h"
+#include "front.hip.h"
 #include "regex.hip.h"
 
 using namespace zke;
@@ -84,14 +85,18 @@ struct zke_engine {
   DevBuf results, meta, rsa_jobs, sha_jobs, rsa_ok, em_dbg, scratch_off, scratch, clean, meta2, scratch2, parts;
   DevBuf misc;   // building-block entry points
   DevBuf key_cache; // KeyCacheEntry[KEY_CACHE_SLOTS]: per-key Montgomery constants, kept across batches
+  DevBuf lanews;  // LaneWs[n]: per-e-mail header table / tag records / tag values of the front kernel
   DevBuf pending; // device counter: e-mails that need another signature round
   std::vector<RegisteredDfa*> dfas;
   // hipGraph replay of the device-mode pipeline (see zke_verify_batch_device)
-  bool use_graphs = true;
+  bool use_graphs = false;          // experimental, off: see zke_verify_batch_device
   hipGraphExec_t graph_exec = nullptr;
   bool graph_key_valid = false;
   GraphKey graph_key{};
   int sha_tile = SHA_TILE;
+  bool front_attr_set = false;
+  bool wave_parse = true;           // front end: one e-mail per wavefront (parse.hip.h); ZKE_LANE_PARSE=1 selects the
+                                    // one-e-mail-per-lane variant (front.hip.h), see DESIGN.md §3
   uint32_t debug_parse_stop = 0;    // ZKE_DEBUG_PARSE_STOP: timing experiments (results are then meaningless)
   uint32_t max_sig_rounds = 4;      // host mode: upper bound, rounds are added only while e-mails are pending
   uint32_t device_mode_rounds = 1;  // device mode: fixed (no read-back)
@@ -184,10 +189,11 @@ int zke_engine_create(const zke_options* opt, zke_engine** out) {
   }
   if (opt && opt->reserved[0]) e->max_sig_rounds = std::min<uint32_t>(opt->reserved[0], 8);
   if (opt && opt->reserved[1]) e->device_mode_rounds = std::min<uint32_t>(opt->reserved[1], 8);
-  if (getenv("ZKE_NO_GRAPHS")) e->use_graphs = false;
+  if (getenv("ZKE_GRAPHS")) e->use_graphs = true;
+  if (getenv("ZKE_LANE_PARSE")) e->wave_parse = false;
   if (const char* st = getenv("ZKE_SHA_TILE")) e->sha_tile = atoi(st);
   if (const char* ds = getenv("ZKE_DEBUG_PARSE_STOP")) e->debug_parse_stop = (uint32_t)atoi(ds);
-  if (opt && opt->reserved[2]) e->use_graphs = false;          // reserved[2] != 0: always launch eagerly
+  if (opt && opt->reserved[2]) e->use_graphs = true;           // reserved[2] != 0: experimental hipGraph replay
   *out = e;
   return 0;
 }
@@ -199,7 +205,7 @@ void zke_engine_destroy(zke_engine* e) {
   DevBuf* bufs[] = {&e->in_raw, &e->in_raw_off, &e->in_dom, &e->in_dom_off, &e->in_key, &e->in_key_off, &e->in_ktype,
                     &e->in_extnull, &e->in_cap_off, &e->in_cap_str_off, &e->in_cap_blob, &e->results, &e->meta,
                     &e->rsa_jobs, &e->sha_jobs, &e->rsa_ok, &e->em_dbg, &e->scratch_off, &e->scratch, &e->clean,
-                    &e->meta2, &e->misc, &e->scratch2, &e->parts, &e->pending, &e->key_cache};
+                    &e->meta2, &e->misc, &e->scratch2, &e->parts, &e->pending, &e->key_cache, &e->lanews};
   for (auto* b : bufs) b->release();
   if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
   for (auto* d : e->dfas) { d->blob.release(); d->dev.release(); delete d; }

@@ -7,6 +7,7 @@ namespace {
 
 constexpr uint32_t SCR_PER_EMAIL = PRE_SLACK + 64;      // fixed part of an e-mail's scratch slot
 constexpr uint32_t CLEAN_PER_EMAIL = 32;
+constexpr size_t FRONT_LDS_BYTES = (size_t)64 * FRONT_ROW;
 
 // scratch_off[i] = align16(2 * (raw_off[i] - raw_off[0])) + i * SCR_PER_EMAIL   (region A then region B, see parse.hip.h)
 // clean_off[i]   = (raw_off[i] - raw_off[0]) + i * CLEAN_PER_EMAIL
@@ -42,7 +43,8 @@ int run_device_pipeline(zke_engine* e, const zke_batch* in, uint64_t raw_total, 
   const size_t scratch_bytes = 2 * (size_t)raw_total + (size_t)(n + 1) * SCR_PER_EMAIL + 256;
   if ((r = e->meta.ensure((size_t)n * sizeof(EmailMeta))) || (r = e->rsa_jobs.ensure((size_t)n * sizeof(RsaJob))) ||
       (r = e->sha_jobs.ensure((size_t)4 * n_pad * sizeof(ShaJob))) || (r = e->rsa_ok.ensure((size_t)n * 4)) ||
-      (r = e->scratch_off.ensure((size_t)(n + 1) * 16)) || (r = e->scratch.ensure(scratch_bytes)) || (r = e->pending.ensure(64)))
+      (r = e->scratch_off.ensure((size_t)(n + 1) * 16)) || (r = e->scratch.ensure(scratch_bytes)) || (r = e->pending.ensure(64)) ||
+      (r = e->lanews.ensure((size_t)n * sizeof(LaneWs))))
     return fail(e, r, "workspace allocation");
   if (want_em && (r = e->em_dbg.ensure((size_t)n * 512))) return fail(e, r, "workspace allocation");
   if (in->with_regex) {
@@ -54,6 +56,10 @@ int run_device_pipeline(zke_engine* e, const zke_batch* in, uint64_t raw_total, 
   uint64_t* scratch_off = e->scratch_off.as<uint64_t>();
   uint64_t* clean_off = scratch_off + (n + 1);
 
+  if (!e->front_attr_set) {
+    HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&front_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FRONT_LDS_BYTES));
+    e->front_attr_set = true;
+  }
   StageTimer tm(e, s);
   tm.mark();
   if (round_begin == 0) {
@@ -80,8 +86,13 @@ int run_device_pipeline(zke_engine* e, const zke_batch* in, uint64_t raw_total, 
 
   const uint32_t rounds = max_rounds;
   for (uint32_t round = round_begin; round < round_end; round++) {
-    ParseArgs pa{B, round, 0, e->debug_parse_stop};
-    hipLaunchKernelGGL(parse_kernel, dim3(n), dim3(64), 0, s, pa);
+    if (e->wave_parse) {
+      ParseArgs pa{B, round, 0, e->debug_parse_stop};
+      hipLaunchKernelGGL(parse_kernel, dim3(n), dim3(64), 0, s, pa);
+    } else {
+      FrontArgs fa{B, e->lanews.as<LaneWs>(), round, 0, e->debug_parse_stop};
+      hipLaunchKernelGGL(front_kernel, dim3((n + 63) / 64), dim3(64), FRONT_LDS_BYTES, s, fa);
+    }
     if (round == 0) tm.mark();
     CanonArgs ca{B, 0};
     hipLaunchKernelGGL(canon_body_kernel, dim3(n), dim3(64), 0, s, ca);
@@ -105,8 +116,13 @@ int run_device_pipeline(zke_engine* e, const zke_batch* in, uint64_t raw_total, 
     B2.meta = e->meta2.as<EmailMeta>();
     B2.scratch = e->scratch2.as<uint8_t>();
     B2.meta_verify = B.meta;
-    ParseArgs pa{B2, 0, 1, 0};
-    hipLaunchKernelGGL(parse_kernel, dim3(n), dim3(64), 0, s, pa);
+    if (e->wave_parse) {
+      ParseArgs pa{B2, 0, 1, 0};
+      hipLaunchKernelGGL(parse_kernel, dim3(n), dim3(64), 0, s, pa);
+    } else {
+      FrontArgs fa{B2, e->lanews.as<LaneWs>(), 0, 1, 0};
+      hipLaunchKernelGGL(front_kernel, dim3((n + 63) / 64), dim3(64), FRONT_LDS_BYTES, s, fa);
+    }
     CanonArgs ca{B2, 1};
     hipLaunchKernelGGL(canon_body_kernel, dim3(n), dim3(64), 0, s, ca);
     QpArgs qa{B2, B.meta, e->clean.as<uint8_t>(), clean_off, B.scratch, B.scratch_off};
@@ -299,9 +315,11 @@ int zke_verify_batch_device(zke_engine* e, const zke_batch* in, uint64_t raw_tot
   if (e->timing || !e->use_graphs)
     return run_device_pipeline(e, in, raw_total, out_dev, s, false, 0, rounds, rounds, true);
 
-  // Launch-bound regime (a 1 024-e-mail batch is ~10 short kernels): a service re-submits batches that live in
-  // the same staging buffers, so the whole kernel sequence is captured into a hipGraph the second time an
-  // identical descriptor is seen and replayed afterwards (one host call per batch instead of ~12).
+  // EXPERIMENTAL, OFF BY DEFAULT (options.reserved[2] / ZKE_GRAPHS=1).  Idea: a service re-submits batches that
+  // live in the same staging buffers, so the kernel sequence could be captured into a hipGraph the second time an
+  // identical descriptor is seen and replayed afterwards.  Measured on MI355X with 16 batches in flight the eager
+  // path is not host-bound (same e-mails/s), and replaying the captured graph faulted in testing (round 1,
+  // tools/devmode_diag.py), so the engine launches eagerly.
   GraphKey key{};
   key.batch = *in; key.raw_total = raw_total; key.out = out_dev; key.rounds = rounds;
   key.n_ids = (uint32_t)(e->host_hdr_ids.size() + e->host_body_ids.size());
