@@ -67,28 +67,54 @@ __global__ __launch_bounds__(64) void canon_body_kernel(CanonArgs A) {
       src_is_raw = 1;
     }
   } else {
+    // 4 consecutive bytes per lane, 256 B per step; the next step's dword is loaded one step ahead.
+    typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+    auto load4 = [&](uint32_t pos) -> uint32_t {       // bytes pos..pos+3 of the body, zero beyond the end
+      if (pos + 4 <= blen) return *(const u32_unaligned*)(body + pos);
+      uint32_t v = 0;
+      for (uint32_t t = 0; t < 4; t++) if (pos + t < blen) v |= (uint32_t)body[pos + t] << (8 * t);
+      return v;
+    };
     uint32_t o = 0;
-    uint32_t cur = (uint32_t)lane < blen ? body[lane] : OOB;
-    uint32_t prev_last = OOB;                 // byte before this chunk
-    for (uint32_t base = 0; base < blen; base += 64) {
-      const uint32_t nl = base + 64 + lane;
-      const uint32_t nxt = nl < blen ? body[nl] : OOB;          // next chunk, in flight while this one is processed
-      const uint32_t c = cur;
-      uint32_t cp = lane_down(c); if (lane == 0) cp = prev_last;
-      uint32_t cn = lane_up(c);
-      const uint32_t nfirst = __builtin_amdgcn_readfirstlane(nxt);
-      if (lane == 63) cn = nfirst;
-      const bool inr = base + lane < blen;
-      const bool w = is_wsp(c);
-      const bool k = inr && !w;
-      const bool s = k && is_wsp(cp) && !(c == '\r' && cn == '\n');
-      const uint64_t Km = __ballot(k), Sm = __ballot(s);
+    uint32_t cur = load4(4 * lane);
+    uint32_t prev_last = OOB;                 // byte before this step's 256-byte window
+    for (uint32_t base = 0; base < blen; base += 256) {
+      const uint32_t nxt = load4(base + 256 + 4 * lane);          // in flight while this window is processed
+      const uint32_t pos0 = base + 4 * lane;
+      uint32_t pv = lane_down(cur >> 24); if (lane == 0) pv = prev_last;       // byte in front of my 4
+      uint32_t nb = lane_up(cur & 0xff);                                          // byte after my 4
+      const uint32_t nfirst = __builtin_amdgcn_readfirstlane(nxt) & 0xff;
+      if (lane == 63) nb = (base + 256 < blen) ? nfirst : OOB;
+      uint32_t outb[8];
+      uint32_t cnt = 0;
+      bool pw = is_wsp(pv);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint32_t c = (cur >> (8 * j)) & 0xff;
+        const uint32_t n = (j < 3) ? ((cur >> (8 * (j + 1))) & 0xff) : nb;
+        const bool inr = pos0 + j < blen;
+        const bool nin = pos0 + j + 1 < blen;
+        const bool w = is_wsp(c);
+        const bool k = inr && !w;
+        const bool sp = k && pw && !(c == '\r' && nin && n == '\n');
+        if (sp) { outb[cnt] = ' '; cnt++; }
+        if (k) { outb[cnt] = c; cnt++; }
+        pw = inr ? w : pw;
+      }
+      // exclusive prefix of cnt (0..8) over the lanes: one ballot per bit of the count
       const uint64_t below = bits_below(lane);
-      const uint32_t off = o + (uint32_t)__builtin_popcountll(Km & below) + (uint32_t)__builtin_popcountll(Sm & below);
-      if (s) { regB[off] = ' '; regB[off + 1] = (uint8_t)c; }
-      else if (k) regB[off] = (uint8_t)c;
-      o += (uint32_t)__builtin_popcountll(Km) + (uint32_t)__builtin_popcountll(Sm);
-      prev_last = __builtin_amdgcn_readlane(c, 63);
+      uint32_t off = 0, total = 0;
+#pragma unroll
+      for (int bit = 0; bit < 4; bit++) {
+        const uint64_t m = __ballot((cnt >> bit) & 1);
+        off += (uint32_t)__builtin_popcountll(m & below) << bit;
+        total += (uint32_t)__builtin_popcountll(m) << bit;
+      }
+#pragma unroll
+      for (int t = 0; t < 8; t++) if ((uint32_t)t < cnt) regB[o + off + t] = (uint8_t)outb[t];
+      o += total;
+      const uint32_t lastlane = __builtin_amdgcn_readlane(cur, 63);
+      prev_last = lastlane >> 24;
       cur = nxt;
     }
     // a WSP run that ends the body is not followed by CRLF: its single SP stays
@@ -115,64 +141,66 @@ __global__ __launch_bounds__(64) void canon_body_kernel(CanonArgs A) {
   }
 }
 
-// ---- verdict of one signature round (thread per e-mail) -------------------------------
-struct FinArgs { BatchDev b; const uint32_t* rsa_ok; uint32_t round, max_rounds; uint32_t* pending; };
+// ---- verdict of one signature round, by the wave that ran the e-mail's RSA job -----------------------
+struct FinArgs { BatchDev b; uint32_t round, max_rounds; uint32_t* pending; };
 
-__global__ void finalize_kernel(FinArgs A) {
+__device__ __forceinline__ void verdict_wave(const FinArgs& A, uint32_t i, bool rsa_ok, int lane) {
   const BatchDev& B = A.b;
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B.n) return;
   EmailMeta* M = B.meta + i;
   zke_result* R = B.results + i;
+  const uint32_t state = M->state;
   uint32_t status, detail;
-  if (M->state == ST_PENDING) return;           // cannot happen after its own round; left for the next
-  if (M->state == ST_FINAL) {
+  if (state == ST_FINAL) {
     status = M->status; detail = M->detail;
   } else {
     // cfdkim verify_email_header: bh compare (as base64 strings), b= decode, RSA verify
     uint32_t err = 0;
     {
-      static const char T[] = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
-      char b64[44];
-      const uint8_t* h = R->body_hash;
-      for (int t = 0; t < 10; t++) {
-        const uint32_t v = ((uint32_t)h[3 * t] << 16) | ((uint32_t)h[3 * t + 1] << 8) | h[3 * t + 2];
-        b64[4 * t] = T[v >> 18]; b64[4 * t + 1] = T[(v >> 12) & 63]; b64[4 * t + 2] = T[(v >> 6) & 63]; b64[4 * t + 3] = T[v & 63];
+      // lane t < 44 produces base64 character t of the 32-byte body hash and compares it with bh=
+      bool bad = false;
+      if (lane < 44) {
+        const uint8_t* h = R->body_hash;
+        const uint32_t g = lane >> 2, k = lane & 3;
+        const uint32_t b0 = h[3 * g], b1 = (3 * g + 1 < 32) ? h[3 * g + 1] : 0u, b2 = (3 * g + 2 < 32) ? h[3 * g + 2] : 0u;
+        const uint32_t v = (b0 << 16) | (b1 << 8) | b2;
+        const uint32_t six = (v >> (18 - 6 * k)) & 63;
+        uint32_t ch = six < 26 ? 'A' + six : (six < 52 ? 'a' + (six - 26) : (six < 62 ? '0' + (six - 52) : (six == 62 ? '+' : '/')));
+        if (lane == 43) ch = '=';
+        bad = M->bh[lane] != (uint8_t)ch;
       }
-      const uint32_t v = ((uint32_t)h[30] << 16) | ((uint32_t)h[31] << 8);
-      b64[40] = T[v >> 18]; b64[41] = T[(v >> 12) & 63]; b64[42] = T[(v >> 6) & 63]; b64[43] = '=';
-      bool same = M->bh_len == 44;
-      for (int t = 0; t < 44 && same; t++) same = M->bh[t] == (uint8_t)b64[t];
-      if (!same) err = ZKE_D_BODY_HASH_MISMATCH;
+      if (__ballot(bad) != 0 || M->bh_len != 44) err = ZKE_D_BODY_HASH_MISMATCH;
     }
     bool unsupported_here = false;
     if (!err && !M->sig_b64_ok) err = ZKE_D_SIG_B64;
     if (!err && M->even_modulus) { err = ZKE_D_U_EVEN_MODULUS; unsupported_here = true; }
-    if (!err && !A.rsa_ok[i]) err = ZKE_D_SIG_MISMATCH;
+    if (!err && !rsa_ok) err = ZKE_D_SIG_MISMATCH;
     if (!err) {
       status = ZKE_OK; detail = 0;
-      R->sig_index = M->cand_sig_index;
+      if (lane == 0) R->sig_index = M->cand_sig_index;
     } else if (M->cand_total > A.round + 1) {
-      if (unsupported_here) M->unsupported = err;
       if (A.round + 1 < A.max_rounds) {
-        M->state = ST_PENDING; M->cand_err = err; R->status = ZKE_DKIM_NOT_PASS; R->detail = err;
-        atomicAdd(A.pending, 1u);
+        if (lane == 0) {
+          if (unsupported_here) M->unsupported = err;
+          M->state = ST_PENDING; M->cand_err = err; R->status = ZKE_DKIM_NOT_PASS; R->detail = err;
+          atomicAdd(A.pending, 1u);
+        }
         return;
       }
       status = ZKE_UNSUPPORTED; detail = ZKE_D_U_TOO_MANY_SIGS;
-      R->sig_index = M->last_touched_sig;
+      if (lane == 0) R->sig_index = M->last_touched_sig;
     } else {
-      R->sig_index = M->last_touched_sig;
+      if (lane == 0) R->sig_index = M->last_touched_sig;
       const uint32_t uns = unsupported_here ? err : M->unsupported;
       if (uns) { status = ZKE_UNSUPPORTED; detail = uns; }
       else { status = ZKE_DKIM_NOT_PASS; detail = M->post_err ? M->post_err : err; }
     }
-    M->state = ST_FINAL; M->status = status; M->detail = detail;
+    if (lane == 0) { M->state = ST_FINAL; M->status = status; M->detail = detail; }
   }
   if (status == ZKE_OK && B.ext_null && B.ext_null[i]) status = ZKE_EXTERNAL_INPUT_NULL;   // circuits.rs:24
-  R->status = status; R->detail = detail;
-  if (status != ZKE_OK && status != ZKE_EXTERNAL_INPUT_NULL) {
-    for (int t = 0; t < 32; t++) { R->from_domain_hash[t] = 0; R->public_key_hash[t] = 0; }
+  if (lane == 0) { R->status = status; R->detail = detail; }
+  if (status != ZKE_OK && status != ZKE_EXTERNAL_INPUT_NULL && lane < 16) {
+    ((uint32_t*)R->from_domain_hash)[lane & 7] = 0;          // lanes 0-7
+    if (lane >= 8) ((uint32_t*)R->public_key_hash)[lane & 7] = 0;
   }
 }
 

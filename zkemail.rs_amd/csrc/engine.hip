@@ -20,6 +20,7 @@
 #include "parse.hip.h"
 #include "front.hip.h"
 #include "regex.hip.h"
+#include "rsa_kernel.hip.h"
 
 using namespace zke;
 
@@ -139,18 +140,16 @@ int launch_sha_any(zke_engine* e, const ShaJob* jobs, uint32_t n, hipStream_t s)
   }
 }
 
-// key_hash_base: &results[0].public_key_hash (same stride as hash_base) or nullptr = no key cache
+// key_hash_base: &results[0].public_key_hash (same stride as hash_base) or nullptr = no key cache;
+// fin.b.results != nullptr: the kernel also writes each e-mail's verdict
 int launch_rsa(zke_engine* e, const RsaJob* jobs, uint32_t n, const uint8_t* hash_base, size_t hash_stride,
-               uint32_t* ok, uint8_t* em, hipStream_t s, bool any_big, const uint8_t* key_hash_base) {
+               uint32_t* ok, uint8_t* em, hipStream_t s, bool any_big, const uint8_t* key_hash_base, const FinArgs& fin) {
   if (n == 0) return 0;
   const uint32_t grid = (n + 3) / 4;
   KeyCacheEntry* cache = key_hash_base ? e->key_cache.as<KeyCacheEntry>() : nullptr;
-  hipLaunchKernelGGL(rsa_verify_kernel<1>, dim3(grid), dim3(256), 0, s, jobs, n, hash_base, hash_stride, ok, em, cache, key_hash_base);
+  (void)any_big;
+  hipLaunchKernelGGL(rsa_verify_kernel, dim3(grid), dim3(256), 0, s, jobs, n, hash_base, hash_stride, ok, em, cache, key_hash_base, fin);
   HIPCHK(e, hipGetLastError());
-  if (any_big) {
-    hipLaunchKernelGGL(rsa_verify_kernel<2>, dim3(grid), dim3(256), 0, s, jobs, n, hash_base, hash_stride, ok, em, cache, key_hash_base);
-    HIPCHK(e, hipGetLastError());
-  }
   return 0;
 }
 
@@ -315,7 +314,7 @@ int zke_rsa_modexp_batch(zke_engine* e, const uint8_t* sig, const uint8_t* mod, 
   hipError_t he = hipMemcpyAsync(dj.p, jobs.data(), jobs.size() * sizeof(RsaJob), hipMemcpyHostToDevice, e->stream);
   if (he == hipSuccess) he = hipMemsetAsync(dh.p, 0, (size_t)n * 32, e->stream);
   if (he == hipSuccess) he = hipMemsetAsync(dem.p, 0, (size_t)n * 512, e->stream);
-  if (he == hipSuccess) r = launch_rsa(e, dj.as<RsaJob>(), n, dh.as<uint8_t>(), 32, dok.as<uint32_t>(), dem.as<uint8_t>(), e->stream, any_big, nullptr);
+  if (he == hipSuccess) r = launch_rsa(e, dj.as<RsaJob>(), n, dh.as<uint8_t>(), 32, dok.as<uint32_t>(), dem.as<uint8_t>(), e->stream, any_big, nullptr, FinArgs{});
   std::vector<uint8_t> emh((size_t)n * 512);
   if (he == hipSuccess && r == 0) he = hipMemcpyAsync(emh.data(), dem.p, emh.size(), hipMemcpyDeviceToHost, e->stream);
   hipError_t hs = hipStreamSynchronize(e->stream);

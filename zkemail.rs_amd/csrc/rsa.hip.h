@@ -204,133 +204,4 @@ __device__ __forceinline__ uint32_t emsa_byte(uint32_t q, uint32_t k, const uint
   return 0xff;
 }
 
-// One wave per job.  blockDim = 256 (4 waves), grid = ceil(n/4).
-// ok_out[i]: 1 = signature verifies (EM == EMSA(hash)), 0 = not.  em_out (optional): EM big-endian, 512 B slots,
-// right-aligned like RsaJob.sig.  hash_base + i*hash_stride -> 32-byte SHA-256 of the header preimage.
-template <int NL>
-__global__ __launch_bounds__(256) void rsa_verify_kernel(const RsaJob* __restrict__ jobs, uint32_t n,
-                                                         const uint8_t* __restrict__ hash_base, size_t hash_stride,
-                                                         uint32_t* __restrict__ ok_out, uint8_t* __restrict__ em_out,
-                                                         KeyCacheEntry* cache, const uint8_t* __restrict__ key_hash_base) {
-  const int lane = threadIdx.x & 63;
-  const uint32_t job = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (job >= n) return;
-  const RsaJob* J = jobs + job;
-  const uint32_t flags = J->flags, k = J->k, bits = J->bits;
-  // this launch handles moduli in (max_bits/2, max_bits]; others belong to the sibling launch
-  const bool mine = (NL == 1) ? (bits <= 2048) : (bits > 2048);
-  if (!mine) return;
-
-  Big<NL> nn, s;
-#pragma unroll
-  for (int q = 0; q < NL; q++) {
-    const uint32_t limb = q * 64 + lane;                    // little-endian limb index
-    const uint32_t boff = 512 - 4 * (limb + 1);             // its big-endian byte offset in the 512-byte field
-    nn.v[q] = __builtin_bswap32(*(const uint32_t*)(J->mod + boff));
-    s.v[q] = __builtin_bswap32(*(const uint32_t*)(J->sig + boff));
-  }
-  uint32_t ok = 0;
-  const bool odd = (__builtin_amdgcn_readfirstlane(nn.v[0]) & 1) != 0;
-  const bool lenok = J->sig_len == k;             // rsa 0.9.6 pkcs1v15::verify: sig_len != pub_key.size() -> Err
-  Big<NL> em;
-#pragma unroll
-  for (int q = 0; q < NL; q++) em.v[q] = 0;
-  if ((flags & RSA_F_ACTIVE) && odd && lenok && bits >= 2 && !big_ge<NL>(s, nn)) {
-    Big<NL> rr;
-    uint32_t ninv = 0;
-    bool hit = false;
-    KeyCacheEntry* E = nullptr;
-    const uint32_t* kh = nullptr;
-    if (cache) {
-      kh = (const uint32_t*)(key_hash_base + (size_t)job * hash_stride);
-      E = cache + (kh[0] % KEY_CACHE_SLOTS);
-      if (__hip_atomic_load(&E->state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2u) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        const bool same = (lane < 8) ? (E->hash[lane] == kh[lane]) : true;
-        if (ballot64(!same) == 0 && E->bits == bits) {
-#pragma unroll
-          for (int q = 0; q < NL; q++) rr.v[q] = E->rr[q * 64 + lane];
-          ninv = E->ninv;
-          hit = true;
-        }
-      }
-    }
-    if (!hit) {
-      // ninv = -n^-1 mod 2^32 (Newton; n odd)
-      uint32_t n0 = __builtin_amdgcn_readfirstlane(nn.v[0]);
-      uint32_t x = n0;
-#pragma unroll
-      for (int i = 0; i < 5; i++) x *= 2 - n0 * x;
-      ninv = 0u - x;
-      // one = R mod n.  2^bits - n, then double (container_bits - bits) times.
-      Big<NL> one;
-      {
-        Big<NL> pw;                                            // 2^bits mod 2^container (0 when bits == container)
-#pragma unroll
-        for (int q = 0; q < NL; q++) {
-          const uint32_t limb = q * 64 + lane;
-          pw.v[q] = (bits < 2048u * NL && (bits >> 5) == limb) ? (1u << (bits & 31)) : 0u;
-        }
-        big_sub<NL>(one, pw, nn, lane);                        // 2^bits - n  (mod 2^container): in [1, n)
-        for (uint32_t i = bits; i < 2048u * NL; i++) mod_double<NL>(one, nn, lane);
-      }
-      rr = one;
-      mod_double<NL>(rr, nn, lane);                            // 2R mod n
-      // (2R)^(2^t) in the Montgomery domain = 2^(2^t) R; t = log2(container bits) -> R*R = R^2 mod n
-      constexpr int T = (NL == 1) ? 11 : 12;
-#pragma unroll 1
-      for (int i = 0; i < T; i++) mont_mul<NL>(rr, rr, rr, nn, ninv, lane);
-      if (cache) {
-        uint32_t won = 0;
-        if (lane == 0) won = atomicCAS(&E->state, 0u, 1u) == 0u ? 1u : 0u;
-        won = __builtin_amdgcn_readfirstlane(won);
-        if (won) {
-          if (lane < 8) E->hash[lane] = kh[lane];
-          if (lane == 0) { E->ninv = ninv; E->bits = bits; }
-#pragma unroll
-          for (int q = 0; q < NL; q++) E->rr[q * 64 + lane] = rr.v[q];
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          if (lane == 0) __hip_atomic_store(&E->state, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
-    }
-    Big<NL> xm;
-    mont_mul<NL>(xm, s, rr, nn, ninv, lane);                 // s in Montgomery form
-    Big<NL> acc = xm;
-    const uint64_t e = J->e | (J->e == 0);                   // e >= 1 (key decode enforces 2 <= e < 2^33)
-    const int top = 63 - __builtin_clzll(e);
-#pragma unroll 1
-    for (int bit = top - 1; bit >= 0; bit--) {
-      mont_mul<NL>(acc, acc, acc, nn, ninv, lane);
-      if ((e >> bit) & 1) mont_mul<NL>(acc, acc, xm, nn, ninv, lane);
-    }
-    Big<NL> lit;
-#pragma unroll
-    for (int q = 0; q < NL; q++) lit.v[q] = (q == 0 && lane == 0) ? 1u : 0u;
-    mont_mul<NL>(em, acc, lit, nn, ninv, lane);              // out of the Montgomery domain
-    // EMSA-PKCS1-v1_5 compare (rsa 0.9.6 pkcs1v15_sign_unpad); needs k >= 19 + 32 + 11
-    const uint32_t* hw = (const uint32_t*)(hash_base + (size_t)job * hash_stride);
-    bool match = k >= 62;
-#pragma unroll
-    for (int q = 0; q < NL; q++) {
-      const uint32_t limb = q * 64 + lane;
-      uint32_t expect = 0;
-#pragma unroll
-      for (int b = 0; b < 4; b++) expect |= emsa_byte(4 * limb + b, k, hw) << (8 * b);
-      match = match && (ballot64(em.v[q] != expect) == 0);
-    }
-    ok = match ? 1u : 0u;
-  }
-  if (lane == 0) ok_out[job] = ok;
-  if (em_out && (flags & RSA_F_ACTIVE)) {     // inactive jobs (later signature rounds) leave the slot alone
-#pragma unroll
-    for (int q = 0; q < NL; q++) {
-      const uint32_t limb = q * 64 + lane;
-      *(uint32_t*)(em_out + (size_t)job * 512 + 512 - 4 * (limb + 1)) = __builtin_bswap32(em.v[q]);
-    }
-    if (NL == 1) *(uint32_t*)(em_out + (size_t)job * 512 + 4 * lane) = 0;   // upper half of the slot
-  }
-}
-
 }  // namespace zke
