@@ -95,8 +95,12 @@ def main():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # ZKE_BENCH_FORCE_DIST=1 exercises the RCCL path (init, all_gather on the step's stream, barrier, all_reduce)
+    # even with one rank, so the N > 1 code can be rehearsed on a one-GPU box
+    use_dist = world > 1 or os.environ.get("ZKE_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     # ---- workload: every rank gets its own seeded batch of the same shape (weak scaling)
@@ -121,7 +125,7 @@ def main():
     engines = [z.Engine(device=local_rank) for _ in range(S)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     results_s = [torch.zeros(n * 192, dtype=torch.uint8, device=dev) for _ in range(S)]
-    gathered_s = [torch.zeros(world * n * 192, dtype=torch.uint8, device=dev) if world > 1 else None for _ in range(S)]
+    gathered_s = [torch.zeros(world * n * 192, dtype=torch.uint8, device=dev) if use_dist else None for _ in range(S)]
     eng, results, gathered = engines[0], results_s[0], gathered_s[0]
     counter = [0]
 
@@ -130,12 +134,12 @@ def main():
         counter[0] += 1
         with torch.cuda.stream(streams[k]):
             engines[k].verify_batch_device(cb, totals[0], totals[1], totals[2], results_s[k].data_ptr(), streams[k].cuda_stream)
-            if world > 1:
+            if use_dist:
                 dist.all_gather_into_tensor(gathered_s[k], results_s[k])
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -147,7 +151,7 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -161,9 +165,10 @@ def main():
         for i in range(0, n, max(1, n // 16)):
             it = wl.inter[i]
             assert bytes(rec[i]["body_hash"]) == it["body_hash"] and bytes(rec[i]["header_hash"]) == it["header_hash"]
-        if world > 1:
+        if use_dist:
             allrec = gathered_s[k].cpu().numpy().view(A.RESULT_DTYPE)
             assert int((allrec["status"] == 0).sum()) == world * n
+            assert allrec[rank * n:(rank + 1) * n].tobytes() == rec.tobytes()
 
     # ---- per-kernel device time, HIP events on the launch stream (second pass, same steps)
     # (one batch at a time on engine 0, so a launch's duration is not stretched by its neighbours)
@@ -240,7 +245,7 @@ def main():
         "config": {"workload": f"BASELINE configs[1]: batch {n} e-mails, 4 KB body, RSA-2048, DKIM-only verify_email"
                    if args.workload == "c2" else f"{args.workload}: {cfg}",
                    "emails_per_step_per_gpu": n, "body_bytes": cfg["body_len"], "rsa_bits": cfg["rsa_bits"],
-                   "inputs": "HBM-resident raw e-mails", "batches_in_flight": S, "collective": "all_gather of 192-B result records (RCCL)" if world > 1 else "none"},
+                   "inputs": "HBM-resident raw e-mails", "batches_in_flight": S, "collective": "all_gather of 192-B result records (RCCL)" if use_dist else "none"},
         "roofline": roof,
         "kernels_us": {k: round(v, 2) for k, v in kern.items()},
         "sha256_saturated": sha_sat,
@@ -274,7 +279,7 @@ def main():
         out["gpu_over_cpu"] = round(emails_per_s / allc, 2)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -73,7 +73,7 @@ enum {
   /* ZKE_CANON_FAIL */
   ZKE_D_NO_SIGNATURE         = 40, /* no DKIM-Signature header at all */
   /* ZKE_UNSUPPORTED */
-  ZKE_D_U_ALGO_SHA1          = 50, /* a=rsa-sha1 */
+  ZKE_D_U_ALGO_SHA1          = 50, /* (unused since a=rsa-sha1 is implemented) */
   ZKE_D_U_ALGO_ED25519       = 51, /* a=ed25519-sha256 or key_type "ed25519" */
   ZKE_D_U_SIG_NON_ASCII      = 52, /* DKIM-Signature value has bytes >= 0x80 (reference goes through from_utf8_lossy) */
   ZKE_D_U_TOO_MANY_HEADERS   = 53, /* more than ZKE_MAX_HEADERS header fields */
@@ -104,6 +104,7 @@ enum {
 #define ZKE_F_HDR_RELAXED  1u
 #define ZKE_F_BODY_RELAXED 2u
 #define ZKE_F_HAS_LENGTH   4u
+#define ZKE_F_SHA1         8u   /* a=rsa-sha1: body_hash / header_hash hold 20-byte SHA-1 digests, zero padded */
 
 /* ------------------------------------------------------------------ result record */
 /* Fixed 192-byte record per email.  from_domain_hash / public_key_hash are the

@@ -137,6 +137,40 @@ void zko_sha256(const uint8_t* data, size_t len, uint8_t out[32]) {
   }
 }
 
+/* ========================================================================= SHA-1 ==
+ * a=rsa-sha1 signatures (cfdkim HashAlgo::RsaSha1 over sha-1 0.10.1, Cargo.lock:2521).  FIPS 180-4 §6.1. */
+#define ROL(x, n) (((x) << (n)) | ((x) >> (32 - (n))))
+void zko_sha1(const uint8_t* data, size_t len, uint8_t out[20]) {
+  uint32_t st[5] = {0x67452301, 0xEFCDAB89, 0x98BADCFE, 0x10325476, 0xC3D2E1F0};
+  const size_t total = ((len + 9 + 63) / 64) * 64;
+  for (size_t off = 0; off < total; off += 64) {
+    uint8_t blk[64];
+    for (size_t i = 0; i < 64; i++) {
+      const size_t p = off + i;
+      uint8_t b = 0;
+      if (p < len) b = data[p];
+      else if (p == len) b = 0x80;
+      else if (p >= total - 8) b = (uint8_t)(((uint64_t)len * 8) >> (8 * (total - 1 - p)));
+      blk[i] = b;
+    }
+    uint32_t w[80];
+    for (int i = 0; i < 16; i++) w[i] = ((uint32_t)blk[4 * i] << 24) | ((uint32_t)blk[4 * i + 1] << 16) | ((uint32_t)blk[4 * i + 2] << 8) | blk[4 * i + 3];
+    for (int i = 16; i < 80; i++) w[i] = ROL(w[i - 3] ^ w[i - 8] ^ w[i - 14] ^ w[i - 16], 1);
+    uint32_t a = st[0], b = st[1], c = st[2], d = st[3], e = st[4];
+    for (int i = 0; i < 80; i++) {
+      uint32_t f, k;
+      if (i < 20) { f = (b & c) | (~b & d); k = 0x5A827999; }
+      else if (i < 40) { f = b ^ c ^ d; k = 0x6ED9EBA1; }
+      else if (i < 60) { f = (b & c) | (b & d) | (c & d); k = 0x8F1BBCDC; }
+      else { f = b ^ c ^ d; k = 0xCA62C1D6; }
+      const uint32_t t = ROL(a, 5) + f + e + k + w[i];
+      e = d; d = c; c = ROL(b, 30); b = a; a = t;
+    }
+    st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e;
+  }
+  for (int i = 0; i < 5; i++) { out[4 * i] = (uint8_t)(st[i] >> 24); out[4 * i + 1] = (uint8_t)(st[i] >> 16); out[4 * i + 2] = (uint8_t)(st[i] >> 8); out[4 * i + 3] = (uint8_t)st[i]; }
+}
+
 /* ====================================================================== base64 ==
  * cfdkim compares base64(body hash) with bh= as strings and decodes b= with
  * base64::engine::general_purpose::STANDARD (padded, canonical, no trailing bits). */
@@ -351,23 +385,29 @@ int zko_parse_rsa_pkcs1(const uint8_t* der, size_t len, uint8_t* mod_out, uint32
 static const uint8_t SHA256_PREFIX[19] = {0x30, 0x31, 0x30, 0x0d, 0x06, 0x09, 0x60, 0x86, 0x48, 0x01,
                                           0x65, 0x03, 0x04, 0x02, 0x01, 0x05, 0x00, 0x04, 0x20};
 
-/* rsa 0.9.6 pkcs1v15::verify + pkcs1v15_sign_unpad */
-int zko_rsa_pkcs1v15_sha256_verify(const uint8_t* mod, uint32_t k, uint64_t e, const uint8_t* sig,
-                                   uint32_t sig_len, const uint8_t hash[32], uint8_t* em_out) {
+static const uint8_t SHA1_PREFIX[15] = {0x30, 0x21, 0x30, 0x09, 0x06, 0x05, 0x2b, 0x0e, 0x03, 0x02, 0x1a, 0x05, 0x00, 0x04, 0x14};
+
+/* rsa 0.9.6 pkcs1v15::verify + pkcs1v15_sign_unpad, DigestInfo prefix of SHA-256 or SHA-1 */
+static int rsa_pkcs1v15_verify(const uint8_t* mod, uint32_t k, uint64_t e, const uint8_t* sig, uint32_t sig_len,
+                               const uint8_t* hash, uint32_t hlen, const uint8_t* prefix, uint32_t plen, uint8_t* em_out) {
   uint8_t em[ZKE_MAX_RSA_BYTES + 8];
   if (em_out) memset(em_out, 0, k);
   if (k == 0 || k > ZKE_MAX_RSA_BYTES) return 0;
   if (sig_len != k) return 0;
   if (zko_rsa_modexp(sig, mod, k, e, em)) return 0; /* sig >= n */
   if (em_out) memcpy(em_out, em, k);
-  const uint32_t tlen = 19 + 32;
+  const uint32_t tlen = plen + hlen;
   if (k < tlen + 11) return 0;
   int ok = em[0] == 0 && em[1] == 1;
-  ok &= memcmp(em + k - 32, hash, 32) == 0;
-  ok &= memcmp(em + k - tlen, SHA256_PREFIX, 19) == 0;
+  ok &= memcmp(em + k - hlen, hash, hlen) == 0;
+  ok &= memcmp(em + k - tlen, prefix, plen) == 0;
   ok &= em[k - tlen - 1] == 0;
   for (uint32_t i = 2; i < k - tlen - 1; i++) ok &= em[i] == 0xff;
   return ok;
+}
+int zko_rsa_pkcs1v15_sha256_verify(const uint8_t* mod, uint32_t k, uint64_t e, const uint8_t* sig,
+                                   uint32_t sig_len, const uint8_t hash[32], uint8_t* em_out) {
+  return rsa_pkcs1v15_verify(mod, k, e, sig, sig_len, hash, 32, SHA256_PREFIX, 19, em_out);
 }
 
 /* =================================================================== mailparse ==
@@ -618,7 +658,7 @@ typedef struct {
 } parsed_t;
 
 typedef struct {
-  int hdr_relaxed, body_relaxed, has_len;
+  int hdr_relaxed, body_relaxed, has_len, sha1;
   uint64_t len_tag;
   uint8_t* preimage; size_t preimage_len;
   uint8_t* cbody; size_t cbody_full, cbody_len;
@@ -715,8 +755,9 @@ static int canon_for_sig(const parsed_t* pm, const uint8_t* sv, size_t svl, cons
   if (algo_unsupported) {
     const tag_t* ta = get_tag(tl, sv, "a");
     *algo_unsupported = 0;
+    c->sha1 = 0;
     if (tag_eq(tl, ta, "rsa-sha256")) {}
-    else if (tag_eq(tl, ta, "rsa-sha1")) *algo_unsupported = ZKE_D_U_ALGO_SHA1;
+    else if (tag_eq(tl, ta, "rsa-sha1")) c->sha1 = 1;
     else if (tag_eq(tl, ta, "ed25519-sha256")) *algo_unsupported = ZKE_D_U_ALGO_ED25519;
     else return ZKE_D_BAD_ALGO;
   }
@@ -1170,18 +1211,21 @@ static void verify_one(const zke_batch* in, uint32_t i, zke_result* out, zke_deb
     if (c == ZKE_D_BAD_CANON || c == ZKE_D_BAD_ALGO) { last_err = (uint32_t)c; continue; }
     if (algo_uns) { unsupported = (uint32_t)algo_uns; continue; }
     if (c) { last_err = (uint32_t)c; continue; }
-    out->flags = (cn.hdr_relaxed ? ZKE_F_HDR_RELAXED : 0) | (cn.body_relaxed ? ZKE_F_BODY_RELAXED : 0) | (cn.has_len ? ZKE_F_HAS_LENGTH : 0);
+    out->flags = (cn.hdr_relaxed ? ZKE_F_HDR_RELAXED : 0) | (cn.body_relaxed ? ZKE_F_BODY_RELAXED : 0) | (cn.has_len ? ZKE_F_HAS_LENGTH : 0) |
+                 (cn.sha1 ? ZKE_F_SHA1 : 0);
     out->canon_header_len = (uint32_t)cn.preimage_len;
     out->canon_body_len = (uint32_t)cn.cbody_len;
-    zko_sha256(cn.cbody, cn.cbody_len, out->body_hash);
-    zko_sha256(cn.preimage, cn.preimage_len, out->header_hash);
+    const uint32_t hlen = cn.sha1 ? 20 : 32;
+    memset(out->body_hash, 0, 32); memset(out->header_hash, 0, 32);
+    if (cn.sha1) { zko_sha1(cn.cbody, cn.cbody_len, out->body_hash); zko_sha1(cn.preimage, cn.preimage_len, out->header_hash); }
+    else { zko_sha256(cn.cbody, cn.cbody_len, out->body_hash); zko_sha256(cn.preimage, cn.preimage_len, out->header_hash); }
     if (dbg) {
       dbg_copy(dbg->canon_header, dbg->canon_header_stride, i, cn.preimage, cn.preimage_len);
       dbg_copy(dbg->canon_body, dbg->canon_body_stride, i, cn.cbody, cn.cbody_full);
       if (dbg->canon_body_full_len) dbg->canon_body_full_len[i] = (uint32_t)cn.cbody_full;
     }
     char b64[48];
-    size_t bl = zko_b64_encode(out->body_hash, 32, b64);
+    size_t bl = zko_b64_encode(out->body_hash, hlen, b64);
     const tag_t* tbh = get_tag(&tl, sv, "bh");
     if (tbh->val_len != bl || memcmp(tl.tagbuf + tbh->val_off, b64, bl)) { last_err = ZKE_D_BODY_HASH_MISMATCH; continue; }
     const tag_t* tb = get_tag(&tl, sv, "b");
@@ -1191,7 +1235,8 @@ static void verify_one(const zke_batch* in, uint32_t i, zke_result* out, zke_deb
     if (!(mod[mod_len - 1] & 1) && !(mod_len == 1 && mod[0] == 0)) { free(sigbuf); unsupported = ZKE_D_U_EVEN_MODULUS; continue; }
     uint8_t em[ZKE_MAX_RSA_BYTES + 8];
     int ok = (mod_len >= 1 && !(mod_len == 1 && mod[0] == 0)) &&
-             zko_rsa_pkcs1v15_sha256_verify(mod, mod_len, e, sigbuf, (uint32_t)sl, out->header_hash, em);
+             rsa_pkcs1v15_verify(mod, mod_len, e, sigbuf, (uint32_t)sl, out->header_hash, hlen,
+                                 cn.sha1 ? SHA1_PREFIX : SHA256_PREFIX, cn.sha1 ? 15 : 19, em);
     if (dbg && dbg->em) dbg_copy(dbg->em, dbg->em_stride, i, em, mod_len);
     free(sigbuf);
     if (!ok) { last_err = ZKE_D_SIG_MISMATCH; continue; }

@@ -23,6 +23,7 @@ extern "C" {
 
 /* core/src/crypto.rs:3-7 hash_bytes */
 void zko_sha256(const uint8_t* data, size_t len, uint8_t out[32]);
+void zko_sha1(const uint8_t* data, size_t len, uint8_t out[20]);
 /* 1 when the SHA-NI path is in use */
 int zko_sha256_uses_shani(void);
 

@@ -117,7 +117,15 @@ def build_cases() -> List[Case]:
     cs.append(mk("fail_bad_query", _hdrs(8), _body(300, 12), k0, SignSpec(extra_tags="q=http; "), status=A.ZKE_DKIM_NOT_PASS, detail=A.D_BAD_QUERY_METHOD, check_inter=False))
     cs.append(mk("fail_bad_canon", _hdrs(8), _body(300, 12), k0, SignSpec(c_tag="nofws/simple"), status=A.ZKE_DKIM_NOT_PASS, detail=A.D_BAD_CANON, check_inter=False))
     cs.append(mk("fail_bad_algo", _hdrs(8), _body(300, 12), k0, SignSpec(algo="rsa-md5"), status=A.ZKE_DKIM_NOT_PASS, detail=A.D_BAD_ALGO, check_inter=False))
-    cs.append(mk("unsupported_sha1", _hdrs(8), _body(300, 12), k0, SignSpec(algo="rsa-sha1"), status=A.ZKE_UNSUPPORTED, detail=A.D_U_ALGO_SHA1, check_inter=False))
+    # a=rsa-sha1: SHA-1 body / header hashes, SHA-1 DigestInfo in the EMSA block
+    for hc, bc in (("relaxed", "relaxed"), ("simple", "simple")):
+        cs.append(mk(f"pass_rsa_sha1_{hc}", _hdrs(8), _body(300, 12), k0, SignSpec(algo="rsa-sha1", header_canon=hc, body_canon=bc)))
+    cs.append(mk("pass_rsa_sha1_1024", _hdrs(8), _body(5000, 13), K("rsa1024_00"), SignSpec(algo="rsa-sha1")))
+    cs.append(mk("fail_rsa_sha1_body", _hdrs(8), _body(300, 12), k0, SignSpec(algo="rsa-sha1"), corrupt="body", status=A.ZKE_DKIM_NOT_PASS, detail=A.D_BODY_HASH_MISMATCH, check_inter=False))
+    cs.append(mk("fail_rsa_sha1_header", _hdrs(8), _body(300, 12), k0, SignSpec(algo="rsa-sha1"), corrupt="header", status=A.ZKE_DKIM_NOT_PASS, detail=A.D_SIG_MISMATCH, check_inter=False))
+    # the algorithm tag lies: hashes made with SHA-256 but a=rsa-sha1 -> body hash cannot match
+    cs.append(mk("fail_sha1_tag_on_sha256_signature", _hdrs(8), _body(300, 12), k0,
+                 mutate=lambda r: r.replace(b"a=rsa-sha256;", b"a=rsa-sha1;", 1), status=A.ZKE_DKIM_NOT_PASS, detail=A.D_BODY_HASH_MISMATCH, check_inter=False))
     cs.append(mk("unsupported_ed25519_alg", _hdrs(8), _body(300, 12), k0, SignSpec(algo="ed25519-sha256"), status=A.ZKE_UNSUPPORTED, detail=A.D_U_ALGO_ED25519, check_inter=False))
     cs.append(mk("unsupported_ed25519_key", _hdrs(8), _body(300, 12), k0, pubkey=b"\x01" * 32, key_type="ed25519", status=A.ZKE_UNSUPPORTED, detail=A.D_U_ALGO_ED25519, check_inter=False))
     cs.append(mk("fail_key_type_unknown", _hdrs(8), _body(300, 12), k0, key_type="dsa", status=A.ZKE_KEY_DECODE_FAIL, detail=A.D_KEY_TYPE, check_inter=False))

@@ -20,6 +20,8 @@ class Oracle:
         lib.zko_sha256.argtypes = [vp, C.c_size_t, vp]
         lib.zko_sha256.restype = None
         lib.zko_sha256_uses_shani.restype = C.c_int
+        lib.zko_sha1.argtypes = [vp, C.c_size_t, vp]
+        lib.zko_sha1.restype = None
         lib.zko_rsa_modexp.argtypes = [vp, vp, C.c_uint32, C.c_uint64, vp]
         lib.zko_rsa_modexp.restype = C.c_int
         lib.zko_parse_rsa_pkcs1.argtypes = [vp, C.c_size_t, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
@@ -55,6 +57,11 @@ class Oracle:
     def sha256(self, data: bytes) -> bytes:
         out = (C.c_uint8 * 32)()
         self.lib.zko_sha256(self._buf(data), len(data), C.addressof(out))
+        return bytes(out)
+
+    def sha1(self, data: bytes) -> bytes:
+        out = (C.c_uint8 * 20)()
+        self.lib.zko_sha1(self._buf(data), len(data), C.addressof(out))
         return bytes(out)
 
     def rsa_modexp(self, sig: bytes, mod: bytes, e: int):

@@ -79,6 +79,7 @@ def test_single_email_entry(engine, oracle):
     dict(n=40, body_len=4096, rsa_bits=4096, n_keys=8, seed=5, qp_frac=0.05),  # config 5 keys
     dict(n=33, body_len=3000, rsa_bits=2048, seed=9, header_canon="simple", body_canon="simple"),
     dict(n=33, body_len=3000, rsa_bits=2048, seed=10, header_canon="relaxed", body_canon="simple", ragged=True),
+    dict(n=150, body_len=9000, rsa_bits=2048, seed=12, ragged=True, invalid_frac=0.15, algo="rsa-sha1"),   # row f4
 ])
 def test_workload_parity(engine, oracle, cfg):
     wl = synth.make_workload("wl", **cfg)

@@ -119,3 +119,11 @@ def test_rsa_pkcs1v15_verify(oracle):
     em2 = bytearray(em); em2[10] = 0
     sig2 = k.sign_em(bytes(em2))
     assert not oracle.rsa_verify(mod, k.e, sig2, digest)[0]
+
+
+def test_sha1_vs_hashlib(oracle):
+    assert oracle.sha1(b"abc").hex() == "a9993e364706816aba3e25717850c26c9cd0d89d"       # FIPS 180-4 example
+    rng = np.random.default_rng(8)
+    for n in list(range(0, 130)) + [1000, 4096, 70000]:
+        m = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        assert oracle.sha1(m) == hashlib.sha1(m).digest(), n

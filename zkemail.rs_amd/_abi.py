@@ -75,7 +75,7 @@ D_U_TOO_MANY_SIGS = 64
 D_U_SIG_B_REPEATED = 65
 
 KEY_RSA, KEY_ED25519, KEY_OTHER = 0, 1, 2
-F_HDR_RELAXED, F_BODY_RELAXED, F_HAS_LENGTH = 1, 2, 4
+F_HDR_RELAXED, F_BODY_RELAXED, F_HAS_LENGTH, F_SHA1 = 1, 2, 4, 8
 
 
 class zke_result(C.Structure):

@@ -135,7 +135,8 @@ __global__ __launch_bounds__(64) void canon_body_kernel(CanonArgs A) {
     M->canon_full_len = full; M->hashed_len = hashed; M->body_src_is_raw = src_is_raw;
     if (A.mode == 0) {
       R->canon_body_len = hashed;
-      ShaJob j; j.src = (uint64_t)(src_is_raw ? body : regB); j.dst = (uint64_t)R->body_hash; j.len = hashed; j.pad = 0;
+      ShaJob j; j.src = (uint64_t)(src_is_raw ? body : regB); j.dst = (uint64_t)R->body_hash; j.len = hashed;
+      j.pad = (flags & ZKE_F_SHA1) ? 1u : 0u;
       B.sha[i] = j;                             // kind 0
     }
   }
@@ -156,19 +157,20 @@ __device__ __forceinline__ void verdict_wave(const FinArgs& A, uint32_t i, bool 
     // cfdkim verify_email_header: bh compare (as base64 strings), b= decode, RSA verify
     uint32_t err = 0;
     {
-      // lane t < 44 produces base64 character t of the 32-byte body hash and compares it with bh=
+      // lane t produces base64 character t of the body hash (32 bytes -> 44 chars, SHA-1: 20 -> 28) and compares it with bh=
+      const uint32_t hl = (M->flags & ZKE_F_SHA1) ? 20u : 32u, nch = (M->flags & ZKE_F_SHA1) ? 28u : 44u;
       bool bad = false;
-      if (lane < 44) {
+      if ((uint32_t)lane < nch) {
         const uint8_t* h = R->body_hash;
         const uint32_t g = lane >> 2, k = lane & 3;
-        const uint32_t b0 = h[3 * g], b1 = (3 * g + 1 < 32) ? h[3 * g + 1] : 0u, b2 = (3 * g + 2 < 32) ? h[3 * g + 2] : 0u;
+        const uint32_t b0 = h[3 * g], b1 = (3 * g + 1 < hl) ? h[3 * g + 1] : 0u, b2 = (3 * g + 2 < hl) ? h[3 * g + 2] : 0u;
         const uint32_t v = (b0 << 16) | (b1 << 8) | b2;
         const uint32_t six = (v >> (18 - 6 * k)) & 63;
         uint32_t ch = six < 26 ? 'A' + six : (six < 52 ? 'a' + (six - 26) : (six < 62 ? '0' + (six - 52) : (six == 62 ? '+' : '/')));
-        if (lane == 43) ch = '=';
+        if ((uint32_t)lane == nch - 1) ch = '=';
         bad = M->bh[lane] != (uint8_t)ch;
       }
-      if (__ballot(bad) != 0 || M->bh_len != 44) err = ZKE_D_BODY_HASH_MISMATCH;
+      if (__ballot(bad) != 0 || M->bh_len != nch) err = ZKE_D_BODY_HASH_MISMATCH;
     }
     bool unsupported_here = false;
     if (!err && !M->sig_b64_ok) err = ZKE_D_SIG_B64;

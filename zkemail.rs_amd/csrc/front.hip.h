@@ -443,8 +443,8 @@ __global__ __launch_bounds__(64) void front_kernel(FrontArgs A) {
   const uint32_t round = A.round;
   const bool verify = A.mode == 0;
 
-  auto sha_job = [&](uint32_t kind, const void* src, uint32_t len, void* dst) {
-    if (verify) { ShaJob j; j.src = (uint64_t)src; j.dst = (uint64_t)dst; j.len = len; j.pad = 0; B.sha[(size_t)kind * B.n_pad + i] = j; }
+  auto sha_job = [&](uint32_t kind, const void* src, uint32_t len, void* dst, uint32_t algo = 0) {
+    if (verify) { ShaJob j; j.src = (uint64_t)src; j.dst = (uint64_t)dst; j.len = len; j.pad = algo; B.sha[(size_t)kind * B.n_pad + i] = j; }
   };
   auto finish = [&](uint32_t status, uint32_t detail) { M->state = ST_FINAL; M->status = status; M->detail = detail; };
 
@@ -568,7 +568,7 @@ __global__ __launch_bounds__(64) void front_kernel(FrontArgs A) {
     }
     if (verify) {
       if (lane_tag_eq(W, TG_A, "rsa-sha256", 10)) {}
-      else if (lane_tag_eq(W, TG_A, "rsa-sha1", 8)) { unsupported = ZKE_D_U_ALGO_SHA1; continue; }
+      else if (lane_tag_eq(W, TG_A, "rsa-sha1", 8)) flags |= ZKE_F_SHA1;
       else if (lane_tag_eq(W, TG_A, "ed25519-sha256", 14)) { unsupported = ZKE_D_U_ALGO_ED25519; continue; }
       else { err_all = ZKE_D_BAD_ALGO; if (have_cand) err_after = err_all; continue; }
     }
@@ -656,7 +656,7 @@ __global__ __launch_bounds__(64) void front_kernel(FrontArgs A) {
     M->cand_sig_index = this_ix; M->cand_hdr = hx; M->flags = flags;
     M->len_tag_lo = (uint32_t)len_tag; M->len_tag_hi = (uint32_t)(len_tag >> 32);
     M->preimage_len = w.o;
-    if (verify) { R->flags = flags; R->canon_header_len = w.o; R->sig_index = this_ix; sha_job(1, regA, w.o, R->header_hash); }
+    if (verify) { R->flags = flags; R->canon_header_len = w.o; R->sig_index = this_ix; sha_job(1, regA, w.o, R->header_hash, (flags & ZKE_F_SHA1) ? 1u : 0u); }
     if (!verify) break;
   }
   if (!verify) {
@@ -673,7 +673,7 @@ __global__ __launch_bounds__(64) void front_kernel(FrontArgs A) {
     return;
   }
   M->state = ST_CAND;
-  J->flags = RSA_F_ACTIVE;
+  J->flags = RSA_F_ACTIVE | ((M->flags & ZKE_F_SHA1) ? (uint32_t)RSA_F_SHA1 : 0u);
 }
 
 }  // namespace zke

@@ -591,9 +591,9 @@ __global__ __launch_bounds__(64) void parse_kernel(ParseArgs A) {
   uint8_t* regA = B.scratch + B.scratch_off[i];
   const uint32_t capA = raw.len + PRE_SLACK;
 
-  auto sha_job = [&](uint32_t kind, const void* src, uint32_t len, void* dst) {
+  auto sha_job = [&](uint32_t kind, const void* src, uint32_t len, void* dst, uint32_t algo = 0) {
     if (lane == 0 && A.mode == 0) {
-      ShaJob j; j.src = (uint64_t)src; j.dst = (uint64_t)dst; j.len = len; j.pad = 0;
+      ShaJob j; j.src = (uint64_t)src; j.dst = (uint64_t)dst; j.len = len; j.pad = algo;
       B.sha[(size_t)kind * B.n_pad + i] = j;
     }
   };
@@ -724,7 +724,7 @@ __global__ __launch_bounds__(64) void parse_kernel(ParseArgs A) {
     }
     if (A.mode == 0) {
       if (tagval_eq(L, TG_A, "rsa-sha256", 10)) {}
-      else if (tagval_eq(L, TG_A, "rsa-sha1", 8)) { unsupported = ZKE_D_U_ALGO_SHA1; continue; }
+      else if (tagval_eq(L, TG_A, "rsa-sha1", 8)) flags |= ZKE_F_SHA1;
       else if (tagval_eq(L, TG_A, "ed25519-sha256", 14)) { unsupported = ZKE_D_U_ALGO_ED25519; continue; }
       else { note_err(ZKE_D_BAD_ALGO); continue; }
     }
@@ -845,7 +845,7 @@ __global__ __launch_bounds__(64) void parse_kernel(ParseArgs A) {
       M->preimage_len = out.o;
       if (A.mode == 0) { R->flags = flags; R->canon_header_len = out.o; R->sig_index = this_ix; }
     }
-    if (A.mode == 0) sha_job(1, regA, out.o, R->header_hash);
+    if (A.mode == 0) sha_job(1, regA, out.o, R->header_hash, (flags & ZKE_F_SHA1) ? 1u : 0u);
     if (A.mode == 1) break;
   }
   if (A.mode == 1) {
@@ -866,8 +866,7 @@ __global__ __launch_bounds__(64) void parse_kernel(ParseArgs A) {
   }
   if (lane == 0) {
     M->state = ST_CAND;
-    uint32_t f = RSA_F_ACTIVE;
-    J->flags = f;
+    J->flags = RSA_F_ACTIVE | ((M->flags & ZKE_F_SHA1) ? (uint32_t)RSA_F_SHA1 : 0u);
   }
 }
 

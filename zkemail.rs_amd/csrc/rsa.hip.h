@@ -37,6 +37,7 @@ static_assert(sizeof(RsaJob) == 1056, "RsaJob layout");
 
 enum : uint32_t {
   RSA_F_ACTIVE = 1,             // run the modexp
+  RSA_F_SHA1 = 2,               // EMSA block carries the SHA-1 DigestInfo and a 20-byte hash (a=rsa-sha1)
 };
 
 // Per-key Montgomery constants, cached across e-mails and batches.  An entry is claimed once
@@ -189,16 +190,19 @@ __device__ __forceinline__ void mod_double(Big<NL>& x, const Big<NL>& n, int lan
 __device__ const uint8_t SHA256_DIGESTINFO[19] = {0x30, 0x31, 0x30, 0x0d, 0x06, 0x09, 0x60, 0x86, 0x48, 0x01,
                                                   0x65, 0x03, 0x04, 0x02, 0x01, 0x05, 0x00, 0x04, 0x20};
 
-// EMSA-PKCS1-v1_5 byte at little-endian position q (q = 0 is the last byte of EM), for SHA-256:
-// EM = 0x00 0x01 FF..FF 0x00 | DigestInfo prefix | H
-__device__ __forceinline__ uint32_t emsa_byte(uint32_t q, uint32_t k, const uint32_t* hash_words) {
+__device__ const uint8_t SHA1_DIGESTINFO[15] = {0x30, 0x21, 0x30, 0x09, 0x06, 0x05, 0x2b, 0x0e, 0x03, 0x02, 0x1a, 0x05, 0x00, 0x04, 0x14};
+
+// EMSA-PKCS1-v1_5 byte at little-endian position q (q = 0 is the last byte of EM):
+// EM = 0x00 0x01 FF..FF 0x00 | DigestInfo prefix | H      (SHA-256: 19 + 32 bytes; SHA-1: 15 + 20)
+__device__ __forceinline__ uint32_t emsa_byte(uint32_t q, uint32_t k, const uint32_t* hash_words, bool sha1) {
+  const uint32_t hl = sha1 ? 20u : 32u, pl = sha1 ? 15u : 19u;
   if (q >= k) return 0;
-  if (q < 32) {
-    const uint32_t bi = 31 - q;                              // byte index in the digest as stored
+  if (q < hl) {
+    const uint32_t bi = hl - 1 - q;                          // byte index in the digest as stored
     return (hash_words[bi >> 2] >> (8 * (bi & 3))) & 0xff;
   }
-  if (q < 51) return SHA256_DIGESTINFO[18 - (q - 32)];
-  if (q == 51) return 0x00;
+  if (q < hl + pl) return sha1 ? SHA1_DIGESTINFO[pl - 1 - (q - hl)] : SHA256_DIGESTINFO[pl - 1 - (q - hl)];
+  if (q == hl + pl) return 0x00;
   if (q == k - 1) return 0x00;
   if (q == k - 2) return 0x01;
   return 0xff;

@@ -108,13 +108,14 @@ __device__ __forceinline__ void rsa_wave(const RsaJob* __restrict__ jobs, uint32
     mont_mul<NL>(em, acc, lit, nn, ninv, lane);              // out of the Montgomery domain
     // EMSA-PKCS1-v1_5 compare (rsa 0.9.6 pkcs1v15_sign_unpad); needs k >= 19 + 32 + 11
     const uint32_t* hw = (const uint32_t*)(hash_base + (size_t)job * hash_stride);
-    bool match = k >= 62;
+    const bool sha1 = (flags & RSA_F_SHA1) != 0;
+    bool match = k >= (sha1 ? 46u : 62u);                    // k >= tLen + 11
 #pragma unroll
     for (int q = 0; q < NL; q++) {
       const uint32_t limb = q * 64 + lane;
       uint32_t expect = 0;
 #pragma unroll
-      for (int b = 0; b < 4; b++) expect |= emsa_byte(4 * limb + b, k, hw) << (8 * b);
+      for (int b = 0; b < 4; b++) expect |= emsa_byte(4 * limb + b, k, hw, sha1) << (8 * b);
       match = match && (ballot64(em.v[q] != expect) == 0);
     }
     ok = match ? 1u : 0u;

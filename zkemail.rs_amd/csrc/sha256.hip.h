@@ -25,9 +25,9 @@ namespace zke {
 
 struct ShaJob {          // one message
   uint64_t src;          // device address of the bytes
-  uint64_t dst;          // device address of the 32-byte digest
+  uint64_t dst;          // device address of the 32-byte digest slot (0 = inactive job)
   uint32_t len;          // bytes
-  uint32_t pad;
+  uint32_t pad;          // 0: SHA-256; 1: SHA-1 (a=rsa-sha1 signatures; 20-byte digest, slot zero padded)
 };
 
 __device__ __forceinline__ uint32_t rotr32(uint32_t x, int n) { return __builtin_amdgcn_alignbit(x, x, n); }
@@ -70,6 +70,31 @@ __device__ __forceinline__ void sha256_compress(uint32_t (&st)[8], uint32_t (&w)
   st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
 }
 
+// SHA-1 (FIPS 180-4 §6.1), same block size and padding as SHA-256; used only for a=rsa-sha1 signatures
+// (cfdkim HashAlgo::RsaSha1 over sha-1 0.10.1).
+__device__ __forceinline__ void sha1_compress(uint32_t (&st)[8], uint32_t (&w)[16]) {
+  uint32_t a = st[0], b = st[1], c = st[2], d = st[3], e = st[4];
+#pragma unroll
+  for (int i = 0; i < 80; i++) {
+    uint32_t wi;
+    if (i < 16) {
+      wi = w[i];
+    } else {
+      const uint32_t x = xor3(w[(i - 3) & 15], w[(i - 8) & 15], w[(i - 14) & 15]) ^ w[i & 15];
+      wi = rotr32(x, 31);
+      w[i & 15] = wi;
+    }
+    uint32_t f, k;
+    if (i < 20) { f = ch3(b, c, d); k = 0x5A827999u; }
+    else if (i < 40) { f = xor3(b, c, d); k = 0x6ED9EBA1u; }
+    else if (i < 60) { f = maj3(b, c, d); k = 0x8F1BBCDCu; }
+    else { f = xor3(b, c, d); k = 0xCA62C1D6u; }
+    const uint32_t t = rotr32(a, 27) + f + e + (k + wi);
+    e = d; d = c; c = rotr32(b, 2); b = a; a = t;
+  }
+  st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e;
+}
+
 typedef uint4 __attribute__((aligned(1))) uint4_unaligned;
 
 // Launch: blockDim = 256 (4 independent waves), grid = ceil(n / 256).
@@ -88,10 +113,10 @@ __global__ __launch_bounds__(256) void sha256_batch_kernel(const ShaJob* __restr
 
   const uint32_t m = (blockIdx.x * 4 + wave) * 64 + lane;
   uint64_t my_src = 0, my_dst = 0;
-  uint32_t my_len = 0, my_nblk = 0;
+  uint32_t my_len = 0, my_nblk = 0, my_algo = 0;
   if (m < n) {
     ShaJob j = jobs[m];
-    my_src = j.src; my_dst = j.dst; my_len = j.len;
+    my_src = j.src; my_dst = j.dst; my_len = j.len; my_algo = j.pad;
     my_nblk = my_dst ? (my_len + 9 + 63) >> 6 : 0;      // dst == 0 marks an inactive job
   }
   *(uint64_t*)(desc + lane * 16) = my_src;
@@ -103,6 +128,8 @@ __global__ __launch_bounds__(256) void sha256_batch_kernel(const ShaJob* __restr
   max_nblk = __builtin_amdgcn_readfirstlane(max_nblk);
 
   uint32_t st[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+  const bool any_sha1 = __ballot(my_algo != 0) != 0;        // wave-uniform: SHA-256-only waves skip the SHA-1 code
+  if (my_algo) { st[0] = 0x67452301; st[1] = 0xEFCDAB89; st[2] = 0x98BADCFE; st[3] = 0x10325476; st[4] = 0xC3D2E1F0; st[5] = st[6] = st[7] = 0; }
   uint8_t* my_row = slab + lane * ROW;
 
   // Software pipeline: the global loads of tile t+1 are issued into registers BEFORE tile t is compressed and
@@ -177,7 +204,7 @@ __global__ __launch_bounds__(256) void sha256_batch_kernel(const ShaJob* __restr
           w[4 * q + 0] = __builtin_bswap32(v.x); w[4 * q + 1] = __builtin_bswap32(v.y);
           w[4 * q + 2] = __builtin_bswap32(v.z); w[4 * q + 3] = __builtin_bswap32(v.w);
         }
-        sha256_compress(st, w);
+        if (any_sha1 && my_algo) sha1_compress(st, w); else sha256_compress(st, w);
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -186,7 +213,7 @@ __global__ __launch_bounds__(256) void sha256_batch_kernel(const ShaJob* __restr
   if (m < n && my_dst) {
     uint32_t* out = (uint32_t*)my_dst;      // digests are 4-byte aligned (result records / engine buffers)
 #pragma unroll
-    for (int i = 0; i < 8; i++) out[i] = __builtin_bswap32(st[i]);
+    for (int i = 0; i < 8; i++) out[i] = (my_algo && i >= 5) ? 0u : __builtin_bswap32(st[i]);
   }
 }
 

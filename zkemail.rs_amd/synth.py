@@ -24,6 +24,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 KEYS_JSON = os.path.join(os.path.dirname(_HERE), "tests", "golden", "keys.json")
 
 SHA256_DIGESTINFO = bytes.fromhex("3031300d060960864801650304020105000420")
+SHA1_DIGESTINFO = bytes.fromhex("3021300906052b0e03021a05000414")
 
 
 # ------------------------------------------------------------------ keys
@@ -138,7 +139,7 @@ def simple_body(body: bytes) -> bytes:
 
 
 def emsa_pkcs1_v15_sha256(digest: bytes, k: int) -> bytes:
-    t = SHA256_DIGESTINFO + digest
+    t = (SHA1_DIGESTINFO if len(digest) == 20 else SHA256_DIGESTINFO) + digest
     return b"\x00\x01" + b"\xff" * (k - len(t) - 3) + b"\x00" + t
 
 
@@ -191,7 +192,8 @@ def sign_email(headers: List[Tuple[bytes, bytes]], body: bytes, key: RsaKey, spe
     follows ``": "`` on the wire (may contain folded ``\\r\\n `` continuations)."""
     cbody_full = relaxed_body(body) if spec.body_canon == "relaxed" else simple_body(body)
     cbody = cbody_full if spec.length is None else cbody_full[:spec.length]
-    bh = base64.b64encode(hashlib.sha256(cbody).digest()).decode()
+    H = hashlib.sha1 if spec.algo == "rsa-sha1" else hashlib.sha256
+    bh = base64.b64encode(H(cbody).digest()).decode()
     ctag = spec.c_tag if spec.c_tag is not None else f"{spec.header_canon}/{spec.body_canon}"
     tags = f"v=1; a={spec.algo}; "
     if not spec.omit_c:
@@ -206,7 +208,7 @@ def sign_email(headers: List[Tuple[bytes, bytes]], body: bytes, key: RsaKey, spe
     hc = relaxed_header if spec.header_canon == "relaxed" else simple_header
     pre = b"".join(hc(n, v) for n, v in select_headers(headers, spec.signed))
     pre += hc(spec.sig_header_name, sig_value_unsigned)[:-2]
-    hh = hashlib.sha256(pre).digest()
+    hh = H(pre).digest()
     em = emsa_pkcs1_v15_sha256(hh, key.k)
     sig = key.sign_em(em)
     b64 = base64.b64encode(sig).decode()
@@ -222,7 +224,7 @@ def sign_email(headers: List[Tuple[bytes, bytes]], body: bytes, key: RsaKey, spe
         raw = raw[:ix] + bytes([raw[ix] ^ 0x01]) + raw[ix + 1:]
     inter = {
         "canon_header": pre, "canon_body": cbody_full, "hashed_body_len": len(cbody),
-        "body_hash": hashlib.sha256(cbody).digest(), "header_hash": hh, "em": em, "sig": sig,
+        "body_hash": H(cbody).digest().ljust(32, b"\0"), "header_hash": hh.ljust(32, b"\0"), "em": em, "sig": sig,
     }
     return raw, inter
 
@@ -304,7 +306,7 @@ class Workload:
 def make_workload(name: str, n: int, body_len: int, rsa_bits: int = 2048, n_keys: int = 16, seed: int = 2,
                   ragged: bool = False, invalid_frac: float = 0.0, qp_frac: float = 0.0,
                   header_canon: str = "relaxed", body_canon: str = "relaxed", domain_fmt: str = "example.com",
-                  hdr_pad: int = 760) -> Workload:
+                  hdr_pad: int = 760, algo: str = "rsa-sha256") -> Workload:
     """Seeded batch of SURVEY §8(d)'s shape: CRLF, c=relaxed/relaxed, a=rsa-sha256,
     h=from:to:subject:date:message-id, one DKIM-Signature, ≈1 KB of headers."""
     rng = np.random.default_rng(seed)
@@ -319,7 +321,7 @@ def make_workload(name: str, n: int, body_len: int, rsa_bits: int = 2048, n_keys
             L = body_len
         body = ascii_body(rng, L, qp_frac=qp_frac)
         hs = std_headers(rng, i, domain_fmt, pad_to=hdr_pad)
-        spec = SignSpec(domain=domain_fmt, header_canon=header_canon, body_canon=body_canon)
+        spec = SignSpec(domain=domain_fmt, header_canon=header_canon, body_canon=body_canon, algo=algo)
         corrupt = None
         if invalid_frac and rng.random() < invalid_frac:
             corrupt = "body" if rng.random() < 0.5 else "header"
