@@ -143,7 +143,7 @@ __global__ __launch_bounds__(64) void canon_body_kernel(CanonArgs A) {
 }
 
 // ---- verdict of one signature round, by the wave that ran the e-mail's RSA job -----------------------
-struct FinArgs { BatchDev b; uint32_t round, max_rounds; uint32_t* pending; };
+struct FinArgs { BatchDev b; uint32_t round, max_rounds; uint32_t* pending; uint32_t debug_skip_rsa; };   // debug_skip_rsa: ablation experiments only
 
 __device__ __forceinline__ void verdict_wave(const FinArgs& A, uint32_t i, bool rsa_ok, int lane) {
   const BatchDev& B = A.b;

@@ -864,6 +864,7 @@ __global__ __launch_bounds__(64) void parse_kernel(ParseArgs A) {
     else finish(ZKE_DKIM_NOT_PASS, err_all ? err_all : (round == 0 ? ZKE_D_NEUTRAL : M->cand_err));
     return;
   }
+  if (A.debug_stop == 7) return;        // ablation: full parse, nothing downstream
   if (lane == 0) {
     M->state = ST_CAND;
     J->flags = RSA_F_ACTIVE | ((M->flags & ZKE_F_SHA1) ? (uint32_t)RSA_F_SHA1 : 0u);

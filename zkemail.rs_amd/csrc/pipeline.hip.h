@@ -99,7 +99,7 @@ int run_device_pipeline(zke_engine* e, const zke_batch* in, uint64_t raw_total, 
     if (round == 0) tm.mark();
     if ((r = launch_sha_any(e, B.sha, 4 * n_pad, s))) return r;
     if (round == 0) tm.mark();
-    FinArgs fa{B, round, rounds, e->pending.as<uint32_t>()};
+    FinArgs fa{B, round, rounds, e->pending.as<uint32_t>(), e->debug_skip_rsa};
     if ((r = launch_rsa(e, B.rsa, n, reinterpret_cast<const uint8_t*>(out_dev) + offsetof(zke_result, header_hash),
                         sizeof(zke_result), nullptr, want_em ? e->em_dbg.as<uint8_t>() : nullptr, s, true,
                         e->key_cache.p ? reinterpret_cast<const uint8_t*>(out_dev) + offsetof(zke_result, public_key_hash) : nullptr, fa)))

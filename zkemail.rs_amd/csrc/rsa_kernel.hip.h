@@ -32,7 +32,7 @@ __device__ __forceinline__ void rsa_wave(const RsaJob* __restrict__ jobs, uint32
   Big<NL> em;
 #pragma unroll
   for (int q = 0; q < NL; q++) em.v[q] = 0;
-  if ((flags & RSA_F_ACTIVE) && odd && lenok && bits >= 2 && !big_ge<NL>(s, nn)) {
+  if ((flags & RSA_F_ACTIVE) && odd && lenok && bits >= 2 && !big_ge<NL>(s, nn) && !fin.debug_skip_rsa) {
     Big<NL> rr;
     uint32_t ninv = 0;
     bool hit = false;

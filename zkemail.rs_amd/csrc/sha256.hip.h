@@ -106,6 +106,11 @@ __global__ __launch_bounds__(256) void sha256_batch_kernel(const ShaJob* __restr
   constexpr int LPR = T / 16;            // lanes that cover one row's tile
   constexpr int RPI = 64 / LPR;          // rows per load instruction
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+  // A message is a serial chain of compressions, so this kernel's duration is set by its longest message, not by
+  // the chip: with several batches in flight its few waves share SIMDs with thousands of front-end / RSA waves and
+  // the chain stretches ~2x.  Raising the wave priority keeps the chain near its unloaded latency; the other
+  // kernels have parallel slack to absorb it.
+  __builtin_amdgcn_s_setprio(3);
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   uint8_t* slab = lds_raw + (size_t)wave * (64 * ROW + 64 * 16);
