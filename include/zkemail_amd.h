@@ -61,7 +61,7 @@ enum {
   ZKE_D_BAD_LENGTH           = 10, /* l= not a decimal usize */
   ZKE_D_BODY_HASH_MISMATCH   = 11, /* base64(SHA-256(canon body)) != bh= */
   ZKE_D_SIG_B64              = 12, /* b= is not canonical padded base64 */
-  ZKE_D_SIG_MISMATCH         = 13, /* RSASSA-PKCS1-v1_5 verification failed */
+  ZKE_D_SIG_MISMATCH         = 13, /* RSASSA-PKCS1-v1_5 / Ed25519 verification failed (an Ed25519 b= that is not 64 bytes included) */
   /* ZKE_PARSE_FAIL */
   ZKE_D_HDR_LEADING_SPACE    = 20, /* header line starts with ' ' */
   ZKE_D_HDR_LONE_CR          = 21, /* headers followed by a lone CR */
@@ -70,11 +70,13 @@ enum {
   ZKE_D_KEY_TYPE             = 30, /* key_type not "rsa"/"ed25519" */
   ZKE_D_KEY_DER              = 31, /* not a DER RSAPublicKey */
   ZKE_D_KEY_RANGE            = 32, /* modulus > 4096 bits, e < 2 or e > 2^33-1 */
+  ZKE_D_KEY_ED25519_POINT    = 33, /* 32-byte Ed25519 key is not a curve point (VerifyingKey::from_bytes fails) */
   /* ZKE_CANON_FAIL */
   ZKE_D_NO_SIGNATURE         = 40, /* no DKIM-Signature header at all */
   /* ZKE_UNSUPPORTED */
   ZKE_D_U_ALGO_SHA1          = 50, /* (unused since a=rsa-sha1 is implemented) */
-  ZKE_D_U_ALGO_ED25519       = 51, /* a=ed25519-sha256 or key_type "ed25519" */
+  ZKE_D_U_ALGO_ED25519       = 51, /* a= and key type disagree (a=ed25519-sha256 with an RSA key, a=rsa-* with an Ed25519
+                                      key): cfdkim errors or verifies against the key type; reported, never guessed */
   ZKE_D_U_SIG_NON_ASCII      = 52, /* DKIM-Signature value has bytes >= 0x80 (reference goes through from_utf8_lossy) */
   ZKE_D_U_TOO_MANY_HEADERS   = 53, /* more than ZKE_MAX_HEADERS header fields */
   ZKE_D_U_PREIMAGE_OVERFLOW  = 54, /* canonicalised header preimage exceeds its scratch slot */
@@ -105,6 +107,7 @@ enum {
 #define ZKE_F_BODY_RELAXED 2u
 #define ZKE_F_HAS_LENGTH   4u
 #define ZKE_F_SHA1         8u   /* a=rsa-sha1: body_hash / header_hash hold 20-byte SHA-1 digests, zero padded */
+#define ZKE_F_ED25519      16u  /* a=ed25519-sha256 with an Ed25519 key (RFC 8463): Ed25519 over the SHA-256 header hash */
 
 /* ------------------------------------------------------------------ result record */
 /* Fixed 192-byte record per email.  from_domain_hash / public_key_hash are the
@@ -241,6 +244,12 @@ int zke_sha256_batch(zke_engine* e, const uint8_t* msg_blob, const uint64_t* off
 int zke_rsa_modexp_batch(zke_engine* e, const uint8_t* sig, const uint8_t* mod,
                          const uint64_t* exp, uint32_t bytes, uint32_t n,
                          uint8_t* em, uint8_t* ok);
+/* n independent Ed25519 verifications under the rule cfdkim applies to k=ed25519 keys (ed25519-dalek 2.1.1
+ * verify_strict, Cargo.lock:778).  keys n x 32 bytes, msgs n x msg_len bytes (msg_len <= 32: DKIM signs the
+ * 32-byte header hash), sigs n x 64 bytes.  out[i]: 0 = key does not decode to a curve point
+ * (VerifyingKey::from_bytes fails), 1 = signature rejected, 2 = valid. */
+int zke_ed25519_verify_batch(zke_engine* e, const uint8_t* keys, const uint8_t* msgs, uint32_t msg_len,
+                             const uint8_t* sigs, uint32_t n, uint32_t* out);
 /* Device-resident SHA-256 micro-benchmark entry: messages already in HBM. */
 int zke_sha256_batch_device(zke_engine* e, const uint8_t* msg_blob_dev, const uint64_t* off_dev,
                             uint32_t n, uint8_t* digests_dev, void* stream);

@@ -742,6 +742,7 @@ static int parse_usize(const uint8_t* s, size_t n, uint64_t* out) {
 
 /* c= / a= / l= handling + both canonicalisations for one validated signature.
  * returns 0 or a ZKE_D_* detail */
+/* *algo_unsupported (historic name) = 1 when a=ed25519-sha256, 0 for the rsa-* algorithms */
 static int canon_for_sig(const parsed_t* pm, const uint8_t* sv, size_t svl, const taglist_t* tl, canon_t* c, int* algo_unsupported) {
   const tag_t* tc = get_tag(tl, sv, "c");
   c->hdr_relaxed = c->body_relaxed = 0;
@@ -758,7 +759,7 @@ static int canon_for_sig(const parsed_t* pm, const uint8_t* sv, size_t svl, cons
     c->sha1 = 0;
     if (tag_eq(tl, ta, "rsa-sha256")) {}
     else if (tag_eq(tl, ta, "rsa-sha1")) c->sha1 = 1;
-    else if (tag_eq(tl, ta, "ed25519-sha256")) *algo_unsupported = ZKE_D_U_ALGO_ED25519;
+    else if (tag_eq(tl, ta, "ed25519-sha256")) *algo_unsupported = 1;      /* RFC 8463: SHA-256 hashes, Ed25519 signature */
     else return ZKE_D_BAD_ALGO;
   }
   c->cbody_full = zko_canon_body(pm->raw + pm->body_off, pm->body_len, c->body_relaxed, c->cbody);
@@ -1175,15 +1176,17 @@ static void verify_one(const zke_batch* in, uint32_t i, zke_result* out, zke_deb
   out->body_offset = (uint32_t)pm.body_off;
 
   uint8_t mod[ZKE_MAX_RSA_BYTES + 8]; uint32_t mod_len = 0; uint64_t e = 0;      /* email.rs:28-29 */
-  if (in->key_type[i] == ZKE_KEY_ED25519) {
+  const int ed_key = in->key_type[i] == ZKE_KEY_ED25519;
+  if (ed_key) {
+    /* VerifyingKey::from_bytes (helpers/src/dkim.rs:103-108 hands over the raw 32 bytes) */
     if (key_len != 32) { out->status = ZKE_KEY_DECODE_FAIL; out->detail = ZKE_D_KEY_DER; return; }
-    out->status = ZKE_UNSUPPORTED; out->detail = ZKE_D_U_ALGO_ED25519; return;
+    if (!zko_ed25519_key_decodes(key)) { out->status = ZKE_KEY_DECODE_FAIL; out->detail = ZKE_D_KEY_ED25519_POINT; return; }
   } else if (in->key_type[i] != ZKE_KEY_RSA) {
     out->status = ZKE_KEY_DECODE_FAIL; out->detail = ZKE_D_KEY_TYPE; return;
   }
-  int kr = zko_parse_rsa_pkcs1(key, key_len, mod, &mod_len, &e);
+  int kr = ed_key ? 0 : zko_parse_rsa_pkcs1(key, key_len, mod, &mod_len, &e);
   if (kr) { out->status = ZKE_KEY_DECODE_FAIL; out->detail = (uint32_t)kr; return; }
-  {
+  if (!ed_key) {
     uint32_t bits = mod_len * 8;
     for (uint8_t t = mod[0]; mod_len && !(t & 0x80) && bits; t <<= 1) bits--;
     out->rsa_bits = (mod_len == 1 && mod[0] == 0) ? 0 : bits;
@@ -1209,10 +1212,11 @@ static void verify_one(const zke_batch* in, uint32_t i, zke_result* out, zke_deb
     int algo_uns = 0;
     int c = canon_for_sig(&pm, sv, svl, &tl, &cn, &algo_uns);
     if (c == ZKE_D_BAD_CANON || c == ZKE_D_BAD_ALGO) { last_err = (uint32_t)c; continue; }
-    if (algo_uns) { unsupported = (uint32_t)algo_uns; continue; }
+    /* a= and the key type must name the same scheme; cfdkim's behaviour for a mixed pair is not restated */
+    if ((algo_uns != 0) != ed_key) { unsupported = ZKE_D_U_ALGO_ED25519; continue; }
     if (c) { last_err = (uint32_t)c; continue; }
     out->flags = (cn.hdr_relaxed ? ZKE_F_HDR_RELAXED : 0) | (cn.body_relaxed ? ZKE_F_BODY_RELAXED : 0) | (cn.has_len ? ZKE_F_HAS_LENGTH : 0) |
-                 (cn.sha1 ? ZKE_F_SHA1 : 0);
+                 (cn.sha1 ? ZKE_F_SHA1 : 0) | (ed_key ? ZKE_F_ED25519 : 0);
     out->canon_header_len = (uint32_t)cn.preimage_len;
     out->canon_body_len = (uint32_t)cn.cbody_len;
     const uint32_t hlen = cn.sha1 ? 20 : 32;
@@ -1232,6 +1236,14 @@ static void verify_one(const zke_batch* in, uint32_t i, zke_result* out, zke_deb
     uint8_t* sigbuf = (uint8_t*)malloc(tb->val_len + 4);
     long sl = zko_b64_decode(tl.tagbuf + tb->val_off, tb->val_len, sigbuf);
     if (sl < 0) { free(sigbuf); last_err = ZKE_D_SIG_B64; continue; }
+    if (ed_key) {
+      /* ed25519-dalek verify_strict over the SHA-256 header hash; a b= that is not 64 bytes cannot be a Signature */
+      int ok = sl == 64 && zko_ed25519_verify_strict(key, out->header_hash, 32, sigbuf);
+      free(sigbuf);
+      if (!ok) { last_err = ZKE_D_SIG_MISMATCH; continue; }
+      passed = 1;
+      continue;
+    }
     if (!(mod[mod_len - 1] & 1) && !(mod_len == 1 && mod[0] == 0)) { free(sigbuf); unsupported = ZKE_D_U_EVEN_MODULUS; continue; }
     uint8_t em[ZKE_MAX_RSA_BYTES + 8];
     int ok = (mod_len >= 1 && !(mod_len == 1 && mod[0] == 0)) &&

@@ -36,6 +36,11 @@ int zko_rsa_pkcs1v15_sha256_verify(const uint8_t* mod, uint32_t mod_len, uint64_
                                    const uint8_t* sig, uint32_t sig_len, const uint8_t hash[32],
                                    uint8_t* em_out /* may be NULL, mod_len bytes */);
 
+/* oracle/zke_ed25519.c — SHA-512 and the ed25519-dalek 2.1.1 rules cfdkim applies to k=ed25519 keys */
+void zko_sha512(const uint8_t* data, size_t len, uint8_t out[64]);
+int zko_ed25519_key_decodes(const uint8_t key[32]);                     /* VerifyingKey::from_bytes */
+int zko_ed25519_verify_strict(const uint8_t key[32], const uint8_t* msg, size_t msg_len, const uint8_t sig[64]);
+
 /* base64 STANDARD (padded, canonical). dec returns length or -1 */
 size_t zko_b64_encode(const uint8_t* in, size_t n, char* out);
 long zko_b64_decode(const uint8_t* in, size_t n, uint8_t* out);

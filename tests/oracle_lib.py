@@ -22,6 +22,12 @@ class Oracle:
         lib.zko_sha256_uses_shani.restype = C.c_int
         lib.zko_sha1.argtypes = [vp, C.c_size_t, vp]
         lib.zko_sha1.restype = None
+        lib.zko_sha512.argtypes = [vp, C.c_size_t, vp]
+        lib.zko_sha512.restype = None
+        lib.zko_ed25519_key_decodes.argtypes = [vp]
+        lib.zko_ed25519_key_decodes.restype = C.c_int
+        lib.zko_ed25519_verify_strict.argtypes = [vp, vp, C.c_size_t, vp]
+        lib.zko_ed25519_verify_strict.restype = C.c_int
         lib.zko_rsa_modexp.argtypes = [vp, vp, C.c_uint32, C.c_uint64, vp]
         lib.zko_rsa_modexp.restype = C.c_int
         lib.zko_parse_rsa_pkcs1.argtypes = [vp, C.c_size_t, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
@@ -63,6 +69,19 @@ class Oracle:
         out = (C.c_uint8 * 20)()
         self.lib.zko_sha1(self._buf(data), len(data), C.addressof(out))
         return bytes(out)
+
+    def sha512(self, data: bytes) -> bytes:
+        out = (C.c_uint8 * 64)()
+        self.lib.zko_sha512(self._buf(data), len(data), C.addressof(out))
+        return bytes(out)
+
+    def ed25519_key_decodes(self, key: bytes) -> bool:
+        assert len(key) == 32
+        return bool(self.lib.zko_ed25519_key_decodes(bytes(key)))
+
+    def ed25519_verify_strict(self, key: bytes, msg: bytes, sig: bytes) -> bool:
+        assert len(key) == 32 and len(sig) == 64
+        return bool(self.lib.zko_ed25519_verify_strict(bytes(key), self._buf(msg), len(msg), bytes(sig)))
 
     def rsa_modexp(self, sig: bytes, mod: bytes, e: int):
         n = len(mod)

@@ -73,3 +73,33 @@ def test_rsa_modexp_mixed_sizes_in_4096_container(engine):
     assert ok.all()
     for g, w in zip(em, want):
         assert bytes(g) == w
+
+
+def test_ed25519_verify_batch_parity(engine, oracle):
+    """Lane-per-signature Ed25519 (ed25519.hip.h) against the Python-integer expectations and the C oracle:
+    valid signatures, bit flips, keys that are not curve points, S >= L, small-order A / R, mixed-order A,
+    non-canonical encodings (tests/ed_vectors.py)."""
+    import ed_vectors
+    vec = ed_vectors.build_vectors()
+    got = engine.ed25519_verify_batch([v[0] for v in vec], [v[1] for v in vec], [v[2] for v in vec])
+    for (k, m, s, exp), g in zip(vec, got):
+        orc = 0 if not oracle.ed25519_key_decodes(k) else (2 if oracle.ed25519_verify_strict(k, m, s) else 1)
+        assert int(g) == exp == orc, (k.hex(), s.hex(), exp, orc, int(g))
+    assert (got == 2).sum() >= 24
+
+
+def test_ed25519_sha1_sized_message(engine, oracle):
+    """a 20-byte message (an rsa-sha1 style header hash) goes through the same one-block SHA-512 path"""
+    from zkemail_rs_amd import ed25519_ref as ed
+    rng = np.random.default_rng(3)
+    keys, msgs, sigs = [], [], []
+    for _ in range(70):                         # more than one wave
+        sd = rng.integers(0, 256, 32, dtype=np.uint8).tobytes()
+        m = rng.integers(0, 256, 20, dtype=np.uint8).tobytes()
+        keys.append(ed.public_key(sd)); msgs.append(m); sigs.append(ed.sign(sd, m))
+    sigs[5] = sigs[6]
+    got = engine.ed25519_verify_batch(keys, msgs, sigs)
+    exp = [2] * 70
+    exp[5] = 1
+    assert list(got) == exp
+    assert oracle.ed25519_verify_strict(keys[0], msgs[0], sigs[0]) and not oracle.ed25519_verify_strict(keys[5], msgs[5], sigs[5])

@@ -57,6 +57,7 @@ D_HDR_LONE_CR = 21
 D_KEY_TYPE = 30
 D_KEY_DER = 31
 D_KEY_RANGE = 32
+D_KEY_ED25519_POINT = 33
 D_NO_SIGNATURE = 40
 D_U_ALGO_SHA1 = 50
 D_U_ALGO_ED25519 = 51
@@ -75,7 +76,7 @@ D_U_TOO_MANY_SIGS = 64
 D_U_SIG_B_REPEATED = 65
 
 KEY_RSA, KEY_ED25519, KEY_OTHER = 0, 1, 2
-F_HDR_RELAXED, F_BODY_RELAXED, F_HAS_LENGTH, F_SHA1 = 1, 2, 4, 8
+F_HDR_RELAXED, F_BODY_RELAXED, F_HAS_LENGTH, F_SHA1, F_ED25519 = 1, 2, 4, 8, 16
 
 
 class zke_result(C.Structure):

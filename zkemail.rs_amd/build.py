@@ -55,11 +55,11 @@ def build_engine(force: bool = False, verbose: bool = False) -> str:
 
 
 def build_oracle(force: bool = False) -> str:
-    src = os.path.join(ROOT, "oracle", "zke_oracle.c")
-    deps = [src, os.path.join(ROOT, "oracle", "zke_oracle.h"), os.path.join(ROOT, "include", "zkemail_amd.h")]
+    srcs = [os.path.join(ROOT, "oracle", "zke_oracle.c"), os.path.join(ROOT, "oracle", "zke_ed25519.c")]
+    deps = srcs + [os.path.join(ROOT, "oracle", "zke_oracle.h"), os.path.join(ROOT, "include", "zkemail_amd.h")]
     if not force and not _newer(ORACLE_SO, deps):
         return ORACLE_SO
-    cmd = ["gcc", "-O3", "-fPIC", "-shared", "-pthread", "-Wall", "-Wextra", "-o", ORACLE_SO, src]
+    cmd = ["gcc", "-O3", "-fPIC", "-shared", "-pthread", "-Wall", "-Wextra", "-o", ORACLE_SO] + srcs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stdout + r.stderr)

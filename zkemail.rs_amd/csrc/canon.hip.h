@@ -151,7 +151,16 @@ __device__ __forceinline__ void verdict_wave(const FinArgs& A, uint32_t i, bool 
   zke_result* R = B.results + i;
   const uint32_t state = M->state;
   uint32_t status, detail;
-  if (state == ST_FINAL) {
+  if (M->ed_key_bad) {
+    // DkimPublicKey::try_from_bytes (email.rs:28-29) fails before any signature is looked at: nothing of the
+    // DKIM scan may show in the record
+    status = ZKE_KEY_DECODE_FAIL; detail = ZKE_D_KEY_ED25519_POINT;
+    if (lane == 0) {
+      M->state = ST_FINAL; M->status = status; M->detail = detail;
+      R->sig_index = 0; R->flags = 0; R->canon_header_len = 0; R->canon_body_len = 0;
+    }
+    if (lane < 16) { ((uint32_t*)R->body_hash)[lane & 7] = 0; if (lane >= 8) ((uint32_t*)R->header_hash)[lane & 7] = 0; }
+  } else if (state == ST_FINAL) {
     status = M->status; detail = M->detail;
   } else {
     // cfdkim verify_email_header: bh compare (as base64 strings), b= decode, RSA verify
@@ -175,7 +184,8 @@ __device__ __forceinline__ void verdict_wave(const FinArgs& A, uint32_t i, bool 
     bool unsupported_here = false;
     if (!err && !M->sig_b64_ok) err = ZKE_D_SIG_B64;
     if (!err && M->even_modulus) { err = ZKE_D_U_EVEN_MODULUS; unsupported_here = true; }
-    if (!err && !rsa_ok) err = ZKE_D_SIG_MISMATCH;
+    const bool sig_ok = (M->flags & ZKE_F_ED25519) ? (M->ed_ok != 0) : rsa_ok;
+    if (!err && !sig_ok) err = ZKE_D_SIG_MISMATCH;
     if (!err) {
       status = ZKE_OK; detail = 0;
       if (lane == 0) R->sig_index = M->cand_sig_index;

@@ -21,6 +21,7 @@
 #include "front.hip.h"
 #include "regex.hip.h"
 #include "rsa_kernel.hip.h"
+#include "ed25519.hip.h"
 
 using namespace zke;
 
@@ -99,6 +100,7 @@ struct zke_engine {
   bool wave_parse = true;           // front end: one e-mail per wavefront (parse.hip.h); ZKE_LANE_PARSE=1 selects the
                                     // one-e-mail-per-lane variant (front.hip.h), see DESIGN.md §3
   uint32_t debug_skip_rsa = 0;      // ZKE_DEBUG_SKIP_RSA: ablation experiments (results are then meaningless)
+  uint32_t debug_skip_ed = 0;       // ZKE_DEBUG_SKIP_ED: ablation, drops the Ed25519 stage launch (Ed25519 e-mails then fail)
   uint32_t debug_parse_stop = 0;    // ZKE_DEBUG_PARSE_STOP: timing experiments (results are then meaningless)
   uint32_t max_sig_rounds = 4;      // host mode: upper bound, rounds are added only while e-mails are pending
   uint32_t device_mode_rounds = 1;  // device mode: fixed (no read-back)
@@ -193,6 +195,7 @@ int zke_engine_create(const zke_options* opt, zke_engine** out) {
   if (getenv("ZKE_LANE_PARSE")) e->wave_parse = false;
   if (const char* st = getenv("ZKE_SHA_TILE")) e->sha_tile = atoi(st);
   if (getenv("ZKE_DEBUG_SKIP_RSA")) e->debug_skip_rsa = 1;
+  if (getenv("ZKE_DEBUG_SKIP_ED")) e->debug_skip_ed = 1;
   if (const char* ds = getenv("ZKE_DEBUG_PARSE_STOP")) e->debug_parse_stop = (uint32_t)atoi(ds);
   if (opt && opt->reserved[2]) e->use_graphs = true;           // reserved[2] != 0: experimental hipGraph replay
   *out = e;
@@ -325,6 +328,35 @@ int zke_rsa_modexp_batch(zke_engine* e, const uint8_t* sig, const uint8_t* mod, 
   if (he != hipSuccess) return fail(e, ZKE_E_DEVICE, "rsa batch", he);
   if (hs != hipSuccess) return fail(e, ZKE_E_DEVICE, "rsa batch sync", hs);
   for (uint32_t i = 0; i < n; i++) memcpy(em + (size_t)i * bytes, emh.data() + (size_t)i * 512 + 512 - bytes, bytes);
+  return 0;
+}
+
+int zke_ed25519_verify_batch(zke_engine* e, const uint8_t* keys, const uint8_t* msgs, uint32_t msg_len,
+                             const uint8_t* sigs, uint32_t n, uint32_t* out) {
+  if (!e) return ZKE_E_ARG;
+  if (n && (!keys || !msgs || !sigs || !out)) return fail(e, ZKE_E_ARG, "ed25519 batch: null pointer");
+  if (msg_len == 0 || msg_len > 32) return fail(e, ZKE_E_ARG, "ed25519 batch: msg_len must be 1..32");
+  if (n == 0) return 0;
+  HIPCHK(e, hipSetDevice(e->device));
+  DevBuf dk, dm, ds, dout;
+  int r = 0;
+  if ((r = dk.ensure((size_t)n * 32)) || (r = dm.ensure((size_t)n * msg_len)) || (r = ds.ensure((size_t)n * 64)) || (r = dout.ensure((size_t)n * 4))) {
+    dk.release(); dm.release(); ds.release(); dout.release();
+    return fail(e, r, "ed25519 batch allocation");
+  }
+  hipError_t he = hipMemcpyAsync(dk.p, keys, (size_t)n * 32, hipMemcpyHostToDevice, e->stream);
+  if (he == hipSuccess) he = hipMemcpyAsync(dm.p, msgs, (size_t)n * msg_len, hipMemcpyHostToDevice, e->stream);
+  if (he == hipSuccess) he = hipMemcpyAsync(ds.p, sigs, (size_t)n * 64, hipMemcpyHostToDevice, e->stream);
+  if (he == hipSuccess) {
+    hipLaunchKernelGGL(ed25519_verify_kernel, dim3((n + 63) / 64), dim3(64), 0, e->stream, dk.as<uint8_t>(), dm.as<uint8_t>(), msg_len,
+                       ds.as<uint8_t>(), n, dout.as<uint32_t>());
+    he = hipGetLastError();
+  }
+  if (he == hipSuccess) he = hipMemcpyAsync(out, dout.p, (size_t)n * 4, hipMemcpyDeviceToHost, e->stream);
+  hipError_t hs = hipStreamSynchronize(e->stream);
+  dk.release(); dm.release(); ds.release(); dout.release();
+  if (he != hipSuccess) return fail(e, ZKE_E_DEVICE, "ed25519 batch", he);
+  if (hs != hipSuccess) return fail(e, ZKE_E_DEVICE, "ed25519 batch sync", hs);
   return 0;
 }
 

@@ -501,16 +501,18 @@ __global__ __launch_bounds__(64) void front_kernel(FrontArgs A) {
     const uint8_t* key = B.key + B.key_off[i];
     const uint32_t key_len = (uint32_t)(B.key_off[i + 1] - B.key_off[i]);
     if (kt == ZKE_KEY_ED25519) {
-      if (key_len != 32) finish(ZKE_KEY_DECODE_FAIL, ZKE_D_KEY_DER); else finish(ZKE_UNSUPPORTED, ZKE_D_U_ALGO_ED25519);
-      return;
+      // raw 32 bytes (helpers/src/dkim.rs:103-108); the curve-point check runs in ed25519_email_kernel
+      if (key_len != 32) { finish(ZKE_KEY_DECODE_FAIL, ZKE_D_KEY_DER); return; }
+      M->key_ok = 2;
+    } else {
+      if (kt != ZKE_KEY_RSA) { finish(ZKE_KEY_DECODE_FAIL, ZKE_D_KEY_TYPE); return; }
+      Rd kr;
+      rd_init(kr, key, key_len);
+      uint32_t bits = 0, even = 0;
+      const uint32_t kerr = lane_decode_key(kr, J, bits, even);
+      if (kerr) { finish(ZKE_KEY_DECODE_FAIL, kerr); return; }
+      R->rsa_bits = bits; M->key_ok = 1; M->even_modulus = even;
     }
-    if (kt != ZKE_KEY_RSA) { finish(ZKE_KEY_DECODE_FAIL, ZKE_D_KEY_TYPE); return; }
-    Rd kr;
-    rd_init(kr, key, key_len);
-    uint32_t bits = 0, even = 0;
-    const uint32_t kerr = lane_decode_key(kr, J, bits, even);
-    if (kerr) { finish(ZKE_KEY_DECODE_FAIL, kerr); return; }
-    R->rsa_bits = bits; M->key_ok = 1; M->even_modulus = even;
     sha_job(2, dom, dom_len, R->from_domain_hash);                            // circuits.rs:16
     sha_job(3, key, key_len, R->public_key_hash);                             // circuits.rs:17
   }
@@ -567,10 +569,13 @@ __global__ __launch_bounds__(64) void front_kernel(FrontArgs A) {
       }
     }
     if (verify) {
+      bool ed_alg = false;
       if (lane_tag_eq(W, TG_A, "rsa-sha256", 10)) {}
       else if (lane_tag_eq(W, TG_A, "rsa-sha1", 8)) flags |= ZKE_F_SHA1;
-      else if (lane_tag_eq(W, TG_A, "ed25519-sha256", 14)) { unsupported = ZKE_D_U_ALGO_ED25519; continue; }
+      else if (lane_tag_eq(W, TG_A, "ed25519-sha256", 14)) ed_alg = true;
       else { err_all = ZKE_D_BAD_ALGO; if (have_cand) err_after = err_all; continue; }
+      if (ed_alg != (B.key_type[i] == ZKE_KEY_ED25519)) { unsupported = ZKE_D_U_ALGO_ED25519; continue; }
+      if (ed_alg) flags |= ZKE_F_ED25519;
     }
     uint64_t len_tag = 0;
     if (present & (1u << TG_L)) {
@@ -673,7 +678,7 @@ __global__ __launch_bounds__(64) void front_kernel(FrontArgs A) {
     return;
   }
   M->state = ST_CAND;
-  J->flags = RSA_F_ACTIVE | ((M->flags & ZKE_F_SHA1) ? (uint32_t)RSA_F_SHA1 : 0u);
+  J->flags = (M->flags & ZKE_F_ED25519) ? 0u : (RSA_F_ACTIVE | ((M->flags & ZKE_F_SHA1) ? (uint32_t)RSA_F_SHA1 : 0u));
 }
 
 }  // namespace zke

@@ -54,10 +54,11 @@ struct EmailMeta {
   uint32_t sig_b64_ok;
   uint32_t bh_len;
   uint8_t  bh[48];            // FWS-stripped bh= (first 48 chars)
-  uint32_t key_ok;            // RSA key decoded
+  uint32_t key_ok;            // 1 = RSA key decoded, 2 = 32-byte Ed25519 key (its point check runs in ed25519_email_kernel)
   uint32_t even_modulus;
   uint32_t reuse;             // mode 1: the first DKIM-Signature is the verified one; scratch of the verify pass is reused
-  uint32_t pad[2];
+  uint32_t ed_key_bad;        // Ed25519 key is not a curve point (VerifyingKey::from_bytes fails): verdict = KEY_DECODE_FAIL
+  uint32_t ed_ok;             // Ed25519 signature of this round's candidate verifies
 };
 static_assert(sizeof(EmailMeta) % 8 == 0, "EmailMeta alignment");
 
@@ -646,14 +647,16 @@ __global__ __launch_bounds__(64) void parse_kernel(ParseArgs A) {
   if (round == 0 && A.mode == 0) {
     const uint32_t kt = B.key_type[i];
     if (kt == ZKE_KEY_ED25519) {
-      if (key.len != 32) finish(ZKE_KEY_DECODE_FAIL, ZKE_D_KEY_DER); else finish(ZKE_UNSUPPORTED, ZKE_D_U_ALGO_ED25519);
-      return;
+      // raw 32 bytes (helpers/src/dkim.rs:103-108); whether they are a curve point is decided by ed25519_email_kernel
+      if (key.len != 32) { finish(ZKE_KEY_DECODE_FAIL, ZKE_D_KEY_DER); return; }
+      if (lane == 0) M->key_ok = 2;
+    } else {
+      if (kt != ZKE_KEY_RSA) { finish(ZKE_KEY_DECODE_FAIL, ZKE_D_KEY_TYPE); return; }
+      uint32_t bits = 0, even = 0;
+      const uint32_t kr = decode_rsa_key(key, J, bits, even);
+      if (kr) { finish(ZKE_KEY_DECODE_FAIL, kr); return; }
+      if (lane == 0) { R->rsa_bits = bits; M->key_ok = 1; M->even_modulus = even; }
     }
-    if (kt != ZKE_KEY_RSA) { finish(ZKE_KEY_DECODE_FAIL, ZKE_D_KEY_TYPE); return; }
-    uint32_t bits = 0, even = 0;
-    const uint32_t kr = decode_rsa_key(key, J, bits, even);
-    if (kr) { finish(ZKE_KEY_DECODE_FAIL, kr); return; }
-    if (lane == 0) { R->rsa_bits = bits; M->key_ok = 1; M->even_modulus = even; }
     // the two output witnesses (core/src/circuits.rs:16-17)
     sha_job(2, dom.base, dom.len, R->from_domain_hash);
     sha_job(3, key.base, key.len, R->public_key_hash);
@@ -723,10 +726,14 @@ __global__ __launch_bounds__(64) void parse_kernel(ParseArgs A) {
       }
     }
     if (A.mode == 0) {
+      bool ed_alg = false;
       if (tagval_eq(L, TG_A, "rsa-sha256", 10)) {}
       else if (tagval_eq(L, TG_A, "rsa-sha1", 8)) flags |= ZKE_F_SHA1;
-      else if (tagval_eq(L, TG_A, "ed25519-sha256", 14)) { unsupported = ZKE_D_U_ALGO_ED25519; continue; }
+      else if (tagval_eq(L, TG_A, "ed25519-sha256", 14)) ed_alg = true;      // RFC 8463: SHA-256 hashes, Ed25519 signature
       else { note_err(ZKE_D_BAD_ALGO); continue; }
+      // a= and the key type must name the same scheme
+      if (ed_alg != (B.key_type[i] == ZKE_KEY_ED25519)) { unsupported = ZKE_D_U_ALGO_ED25519; continue; }
+      if (ed_alg) flags |= ZKE_F_ED25519;
     }
     uint64_t len_tag = 0;
     if (present & (1u << TG_L)) {
@@ -867,7 +874,8 @@ __global__ __launch_bounds__(64) void parse_kernel(ParseArgs A) {
   if (A.debug_stop == 7) return;        // ablation: full parse, nothing downstream
   if (lane == 0) {
     M->state = ST_CAND;
-    J->flags = RSA_F_ACTIVE | ((M->flags & ZKE_F_SHA1) ? (uint32_t)RSA_F_SHA1 : 0u);
+    // an Ed25519 candidate leaves the RSA job inactive; ed25519_email_kernel verifies it
+    J->flags = (M->flags & ZKE_F_ED25519) ? 0u : (RSA_F_ACTIVE | ((M->flags & ZKE_F_SHA1) ? (uint32_t)RSA_F_SHA1 : 0u));
   }
 }
 

@@ -99,6 +99,10 @@ int run_device_pipeline(zke_engine* e, const zke_batch* in, uint64_t raw_total, 
     if (round == 0) tm.mark();
     if ((r = launch_sha_any(e, B.sha, 4 * n_pad, s))) return r;
     if (round == 0) tm.mark();
+    if (!e->debug_skip_ed) {
+      EdArgs ea{B, round};        // Ed25519 keys / signatures (lane per e-mail); all-RSA waves exit after one load
+      hipLaunchKernelGGL(ed25519_email_kernel, dim3((n + 63) / 64), dim3(64), 0, s, ea);
+    }
     FinArgs fa{B, round, rounds, e->pending.as<uint32_t>(), e->debug_skip_rsa};
     if ((r = launch_rsa(e, B.rsa, n, reinterpret_cast<const uint8_t*>(out_dev) + offsetof(zke_result, header_hash),
                         sizeof(zke_result), nullptr, want_em ? e->em_dbg.as<uint8_t>() : nullptr, s, true,

@@ -18,7 +18,7 @@ from ._abi import (CompiledRegex, DebugBuffers, Email, EmailVerifierOutput, Emai
                    EmailWithRegexVerifierOutput, PackedBatch)
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_PKG, "libzkemail_amd.so")
+_LIB_PATH = os.environ.get("ZKE_LIB") or os.path.join(_PKG, "libzkemail_amd.so")   # ZKE_LIB: A/B runs of two builds
 _lib = None
 
 
@@ -72,6 +72,8 @@ def load_library(path: Optional[str] = None):
     lib.zke_sha256_batch_device.restype = C.c_int
     lib.zke_rsa_modexp_batch.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_uint32, vp, vp]
     lib.zke_rsa_modexp_batch.restype = C.c_int
+    lib.zke_ed25519_verify_batch.argtypes = [vp, vp, vp, C.c_uint32, vp, C.c_uint32, vp]
+    lib.zke_ed25519_verify_batch.restype = C.c_int
     lib.zke_version.argtypes = []
     lib.zke_version.restype = C.c_char_p
     lib.zke_device_available.argtypes = []
@@ -85,6 +87,7 @@ EXPORTED_SYMBOLS = [
     "zke_engine_create", "zke_engine_destroy", "zke_last_error", "zke_dfa_register", "zke_verify_batch",
     "zke_verify_batch_device", "zke_engine_sync", "zke_get_timings", "zke_set_timing", "zke_verify_email",
     "zke_sha256_batch", "zke_sha256_batch_device", "zke_rsa_modexp_batch", "zke_version", "zke_device_available",
+    "zke_ed25519_verify_batch",
 ]
 
 
@@ -176,6 +179,19 @@ class Engine:
         self._check(self.lib.zke_rsa_modexp_batch(self.h, s.ctypes.data, m.ctypes.data, e.ctypes.data, nbytes, n,
                                                   em.ctypes.data, ok.ctypes.data), "zke_rsa_modexp_batch")
         return em, ok
+
+    def ed25519_verify_batch(self, keys: Sequence[bytes], msgs: Sequence[bytes], sigs: Sequence[bytes]) -> np.ndarray:
+        """0 = key does not decode, 1 = rejected, 2 = valid (ed25519-dalek verify_strict); equal-length messages <= 32 B."""
+        n = len(keys)
+        ml = len(msgs[0]) if n else 32
+        assert all(len(k) == 32 for k in keys) and all(len(x) == 64 for x in sigs) and all(len(m) == ml for m in msgs)
+        k = np.frombuffer(b"".join(keys), np.uint8).copy()
+        m = np.frombuffer(b"".join(msgs), np.uint8).copy()
+        g = np.frombuffer(b"".join(sigs), np.uint8).copy()
+        out = np.zeros(n, np.uint32)
+        self._check(self.lib.zke_ed25519_verify_batch(self.h, k.ctypes.data, m.ctypes.data, ml, g.ctypes.data, n,
+                                                      out.ctypes.data), "zke_ed25519_verify_batch")
+        return out
 
     # ---- zkemail_core mirror
     def verify_emails(self, emails: Sequence[Email]) -> np.ndarray:

@@ -13,7 +13,7 @@ import hashlib
 import json
 import os
 import re
-from dataclasses import dataclass
+from dataclasses import dataclass, replace
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -51,6 +51,31 @@ class RsaKey:
         h = (qinv * (m1 - m2)) % self.p
         s = m2 + h * self.q
         return s.to_bytes(self.k, "big")
+
+
+@dataclass
+class EdKey:
+    """Ed25519 DKIM key (RFC 8463): the 32 raw public-key bytes are what helpers/src/dkim.rs:53-56 hands to core."""
+    name: str
+    seed: bytes
+    pub: bytes
+
+    @property
+    def pkcs1_der(self) -> bytes:      # the `PublicKey.key` bytes of this key, whatever the key type
+        return self.pub
+
+    key_type = "ed25519"
+
+
+def ed_keys(count: int, seed: int = 25519) -> List["EdKey"]:
+    """Deterministic Ed25519 keys (seeds from a seeded generator; public keys by ed25519_ref, RFC 8032 §5.1.5)."""
+    from . import ed25519_ref as ed
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(count):
+        sd = rng.integers(0, 256, 32, dtype=np.uint8).tobytes()
+        out.append(EdKey(f"ed25519_{i:02d}", sd, ed.public_key(sd)))
+    return out
 
 
 def der_len(n: int) -> bytes:
@@ -167,6 +192,7 @@ class SignSpec:
     sig_header_name: bytes = b"DKIM-Signature"
     c_tag: Optional[str] = None            # override the c= spelling ("relaxed", None = a/b)
     omit_c: bool = False
+    keep_algo: bool = False                # Ed25519 key: keep `algo` as written instead of "ed25519-sha256"
 
 
 def select_headers(headers: List[Tuple[bytes, bytes]], names: Sequence[str]) -> List[Tuple[bytes, bytes]]:
@@ -193,6 +219,8 @@ def sign_email(headers: List[Tuple[bytes, bytes]], body: bytes, key: RsaKey, spe
     cbody_full = relaxed_body(body) if spec.body_canon == "relaxed" else simple_body(body)
     cbody = cbody_full if spec.length is None else cbody_full[:spec.length]
     H = hashlib.sha1 if spec.algo == "rsa-sha1" else hashlib.sha256
+    if isinstance(key, EdKey) and spec.algo == "rsa-sha256" and not spec.keep_algo:
+        spec = replace(spec, algo="ed25519-sha256")
     bh = base64.b64encode(H(cbody).digest()).decode()
     ctag = spec.c_tag if spec.c_tag is not None else f"{spec.header_canon}/{spec.body_canon}"
     tags = f"v=1; a={spec.algo}; "
@@ -209,8 +237,12 @@ def sign_email(headers: List[Tuple[bytes, bytes]], body: bytes, key: RsaKey, spe
     pre = b"".join(hc(n, v) for n, v in select_headers(headers, spec.signed))
     pre += hc(spec.sig_header_name, sig_value_unsigned)[:-2]
     hh = H(pre).digest()
-    em = emsa_pkcs1_v15_sha256(hh, key.k)
-    sig = key.sign_em(em)
+    if isinstance(key, EdKey):         # RFC 8463 §3: the Ed25519 message is the SHA-256 header hash
+        from . import ed25519_ref as ed
+        em, sig = b"", ed.sign(key.seed, hh)
+    else:
+        em = emsa_pkcs1_v15_sha256(hh, key.k)
+        sig = key.sign_em(em)
     b64 = base64.b64encode(sig).decode()
     sig_field = fold_b64(b64, 72 - 3) if spec.fold_sig else b64.encode()
     sig_value = sig_value_unsigned + sig_field
@@ -310,7 +342,7 @@ def make_workload(name: str, n: int, body_len: int, rsa_bits: int = 2048, n_keys
     """Seeded batch of SURVEY §8(d)'s shape: CRLF, c=relaxed/relaxed, a=rsa-sha256,
     h=from:to:subject:date:message-id, one DKIM-Signature, ≈1 KB of headers."""
     rng = np.random.default_rng(seed)
-    keys = keys_of(rsa_bits, n_keys)
+    keys = ed_keys(n_keys) if algo == "ed25519-sha256" else keys_of(rsa_bits, n_keys)
     emails, inter, bsum, rsum = [], [], 0, 0
     for i in range(n):
         key = keys[i % len(keys)]
@@ -327,7 +359,7 @@ def make_workload(name: str, n: int, body_len: int, rsa_bits: int = 2048, n_keys
             corrupt = "body" if rng.random() < 0.5 else "header"
         raw, it = sign_email(hs, body, key, spec, corrupt=corrupt)
         it["corrupt"] = corrupt
-        emails.append(Email(domain_fmt, raw, PublicKey(key.pkcs1_der, "rsa")))
+        emails.append(Email(domain_fmt, raw, PublicKey(key.pkcs1_der, getattr(key, "key_type", "rsa"))))
         inter.append(it)
         bsum += it["hashed_body_len"]
         rsum += len(raw)
