@@ -38,11 +38,14 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c4shard", "c5"],
-                    help="c2 = BASELINE configs[1] (default); c4shard = one GPU's shard of configs[3]; c5 = configs[4] shape")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c4shard", "c5", "c2ed"],
+                    help="c2 = BASELINE configs[1] (default); c4shard = one GPU's shard of configs[3]; c5 = configs[4] shape; "
+                         "c2ed = the c2 shape signed a=ed25519-sha256 (SURVEY §8(f) row f4)")
     ap.add_argument("--batch", type=int, default=0, help="override e-mails per step (default: the config's batch)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU baseline sample budget per leg")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-saturated", action="store_true",
+                    help="skip the chip-filling SHA-256 micro-benchmark (profile runs: keeps the kernel stats to the workload's launches)")
     ap.add_argument("--streams", type=int, default=20,
                     help="batches in flight per GPU: step i runs on engine/stream i %% S (each engine owns its workspace); "
                          "1 = strictly serial steps")
@@ -108,6 +111,7 @@ def main():
         "c2": dict(n=1024, body_len=4096, rsa_bits=2048, n_keys=16),
         "c4shard": dict(n=8192, body_len=65536, rsa_bits=2048, n_keys=16),
         "c5": dict(n=2048, body_len=4096, rsa_bits=4096, n_keys=16, qp_frac=0.05),
+        "c2ed": dict(n=1024, body_len=4096, n_keys=16, algo="ed25519-sha256"),
     }
     cfg = dict(cfgs[args.workload])
     if args.batch:
@@ -211,7 +215,7 @@ def main():
     # ---- the same SHA-256 kernel with enough independent messages to fill the chip (kernel capability, not the
     # workload's roofline): 2^18 messages x 4 KiB resident in HBM, HIP-event timed on the launch stream
     sha_sat = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_saturated:
         nm, ml = 1 << 18, 4096
         blob = torch.randint(0, 256, (nm * ml + 64,), dtype=torch.uint8, device=dev)
         off = (torch.arange(nm + 1, dtype=torch.int64, device=dev) * ml)
@@ -245,7 +249,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[1]: batch {n} e-mails, 4 KB body, RSA-2048, DKIM-only verify_email"
                    if args.workload == "c2" else f"{args.workload}: {cfg}",
-                   "emails_per_step_per_gpu": n, "body_bytes": cfg["body_len"], "rsa_bits": cfg["rsa_bits"],
+                   "emails_per_step_per_gpu": n, "body_bytes": cfg["body_len"], "rsa_bits": cfg.get("rsa_bits", 0), "algo": cfg.get("algo", "rsa-sha256"),
                    "inputs": "HBM-resident raw e-mails", "batches_in_flight": S, "collective": "all_gather of 192-B result records (RCCL)" if use_dist else "none"},
         "roofline": roof,
         "kernels_us": {k: round(v, 2) for k, v in kern.items()},

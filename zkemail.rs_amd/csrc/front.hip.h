@@ -458,7 +458,8 @@ __global__ __launch_bounds__(64) void front_kernel(FrontArgs A) {
   const uint32_t raw_len = (uint32_t)(r1 - r0);
   const uint8_t* dom = B.dom + B.dom_off[i];
   const uint32_t dom_len = (uint32_t)(B.dom_off[i + 1] - B.dom_off[i]);
-  uint8_t* regA = B.scratch + B.scratch_off[i];
+  if (round == 0 && verify) batch_prologue(B, i, true, i == 0, 0, 1);
+  uint8_t* regA = B.scratch + scratch_offset(r0 - B.raw_off[0], i);
   const uint32_t capA = raw_len + PRE_SLACK;
 
   if (!verify) {

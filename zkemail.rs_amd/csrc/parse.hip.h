@@ -78,10 +78,42 @@ struct BatchDev {
   ShaJob* sha;                // kind-major: sha[kind * n_pad + i], kinds 0 body, 1 header, 2 domain, 3 key
   uint32_t n_pad;
   uint8_t* scratch;           // per e-mail: region A (preimage) then region B (canonical body)
-  const uint64_t* scratch_off;// [n+1]; region A = raw_len + PRE_SLACK bytes, region B = raw_len + 16
+  uint64_t* scratch_off;      // [n+1]; region A = raw_len + PRE_SLACK bytes, region B = raw_len + 16 (written by the round-0 front end)
+  uint64_t* clean_off;        // [n+1]; offsets of the QP-cleaned bodies (regex stage), written alongside
+  uint32_t* pending;          // e-mails waiting for another signature round (reset by the round-0 front end)
   const EmailMeta* meta_verify; // mode 1 only: the verify pass's meta
 };
 constexpr uint32_t PRE_SLACK = 1024;
+constexpr uint32_t SCR_PER_EMAIL = PRE_SLACK + 64;      // fixed part of an e-mail's scratch slot
+constexpr uint32_t CLEAN_PER_EMAIL = 32;
+
+// scratch_off[i] = align16(2 * (raw_off[i] - raw_off[0])) + i * SCR_PER_EMAIL   (region A then region B)
+// clean_off[i]   = (raw_off[i] - raw_off[0]) + i * CLEAN_PER_EMAIL
+__host__ __device__ inline uint64_t scratch_offset(uint64_t rel, uint32_t i) { return ((2 * rel + 15) & ~15ull) + (uint64_t)i * SCR_PER_EMAIL; }
+__host__ __device__ inline uint64_t clean_offset(uint64_t rel, uint32_t i) { return rel + (uint64_t)i * CLEAN_PER_EMAIL; }
+
+// Round-0 bookkeeping of a batch, done by the front-end kernel itself instead of three tiny launches (an offsets
+// kernel and two memsets, each a dispatch that queues behind the other batches in flight): the thread that owns
+// e-mail i publishes its two offsets; `lead` threads (t of nt, all in the block that owns e-mail 0) clear the
+// SHA jobs of the padding lanes of each kind's last wave, the (n+1)-th offsets and the pending counter.
+__device__ __forceinline__ void batch_prologue(const BatchDev& B, uint32_t i, bool owner, bool lead, uint32_t t, uint32_t nt) {
+  const uint64_t base = B.raw_off[0];
+  if (owner) {
+    const uint64_t rel = B.raw_off[i] - base;
+    B.scratch_off[i] = scratch_offset(rel, i);
+    B.clean_off[i] = clean_offset(rel, i);
+  }
+  if (lead) {
+    for (uint32_t k = 0; k < 4; k++)
+      for (uint32_t o = B.n + t; o < B.n_pad; o += nt) { ShaJob z{0, 0, 0, 0}; B.sha[(size_t)k * B.n_pad + o] = z; }
+    if (t == 0) {
+      const uint64_t rel = B.raw_off[B.n] - base;
+      B.scratch_off[B.n] = scratch_offset(rel, B.n);
+      B.clean_off[B.n] = clean_offset(rel, B.n);
+      *B.pending = 0;
+    }
+  }
+}
 constexpr uint32_t PARSE_STAGE_BYTES = 4096;   // header blocks beyond this are read from HBM past the staged part
 
 // ------------------------------------------------------------------ byte strings and windows
@@ -574,6 +606,7 @@ __global__ __launch_bounds__(64) void parse_kernel(ParseArgs A) {
   }
 
   const uint64_t r0 = B.raw_off[i], r1 = B.raw_off[i + 1];
+  if (round == 0 && A.mode == 0) batch_prologue(B, i, lane == 0, i == 0, (uint32_t)lane, 64);
   Str raw = mkstr(B.raw + r0, (uint32_t)(r1 - r0));
   {
     // Stage the head of the e-mail in LDS with 16-byte lane-contiguous loads: every later scan of the header
@@ -589,7 +622,7 @@ __global__ __launch_bounds__(64) void parse_kernel(ParseArgs A) {
   if (A.debug_stop == 1) return;
   const Str dom = mkstr(B.dom + B.dom_off[i], (uint32_t)(B.dom_off[i + 1] - B.dom_off[i]));
   const Str key = mkstr(B.key + B.key_off[i], (uint32_t)(B.key_off[i + 1] - B.key_off[i]));
-  uint8_t* regA = B.scratch + B.scratch_off[i];
+  uint8_t* regA = B.scratch + scratch_offset(r0 - B.raw_off[0], i);
   const uint32_t capA = raw.len + PRE_SLACK;
 
   auto sha_job = [&](uint32_t kind, const void* src, uint32_t len, void* dst, uint32_t algo = 0) {

@@ -5,24 +5,9 @@
 
 namespace {
 
-constexpr uint32_t SCR_PER_EMAIL = PRE_SLACK + 64;      // fixed part of an e-mail's scratch slot
-constexpr uint32_t CLEAN_PER_EMAIL = 32;
 constexpr size_t FRONT_LDS_BYTES = (size_t)64 * FRONT_ROW;
 
-// scratch_off[i] = align16(2 * (raw_off[i] - raw_off[0])) + i * SCR_PER_EMAIL   (region A then region B, see parse.hip.h)
-// clean_off[i]   = (raw_off[i] - raw_off[0]) + i * CLEAN_PER_EMAIL
-__global__ void offsets_kernel(const uint64_t* raw_off, uint32_t n, uint64_t* scratch_off, uint64_t* clean_off) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i > n) return;
-  const uint64_t rel = raw_off[i] - raw_off[0];
-  scratch_off[i] = ((2 * rel + 15) & ~15ull) + (uint64_t)i * SCR_PER_EMAIL;
-  clean_off[i] = rel + (uint64_t)i * CLEAN_PER_EMAIL;
-}
-
-inline uint64_t host_scratch_off(const uint64_t* raw_off, uint32_t i) {
-  const uint64_t rel = raw_off[i] - raw_off[0];
-  return ((2 * rel + 15) & ~15ull) + (uint64_t)i * SCR_PER_EMAIL;
-}
+inline uint64_t host_scratch_off(const uint64_t* raw_off, uint32_t i) { return scratch_offset(raw_off[i] - raw_off[0], i); }
 
 struct StageTimer {
   zke_engine* e; hipStream_t s; int k = 0; bool on;
@@ -62,12 +47,7 @@ int run_device_pipeline(zke_engine* e, const zke_batch* in, uint64_t raw_total, 
   }
   StageTimer tm(e, s);
   tm.mark();
-  if (round_begin == 0) {
-    hipLaunchKernelGGL(offsets_kernel, dim3((n + 1 + 255) / 256), dim3(256), 0, s, in->raw_off, n, scratch_off, clean_off);
-    // jobs of the padding lanes of the last wave of each kind must read as inactive
-    HIPCHK(e, hipMemsetAsync(e->sha_jobs.p, 0, (size_t)4 * n_pad * sizeof(ShaJob), s));
-    HIPCHK(e, hipMemsetAsync(e->pending.p, 0, 8, s));
-  }
+  // (offsets, padding SHA jobs and the pending counter are initialised by the round-0 front-end kernel: batch_prologue)
 
   BatchDev B{};
   B.n = n;
@@ -82,6 +62,8 @@ int run_device_pipeline(zke_engine* e, const zke_batch* in, uint64_t raw_total, 
   B.n_pad = n_pad;
   B.scratch = e->scratch.as<uint8_t>();
   B.scratch_off = scratch_off;
+  B.clean_off = clean_off;
+  B.pending = e->pending.as<uint32_t>();
   B.meta_verify = nullptr;
 
   const uint32_t rounds = max_rounds;
