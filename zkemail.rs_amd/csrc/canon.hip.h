@@ -40,21 +40,18 @@ __device__ __forceinline__ uint32_t trailing_crlf_pairs(LD load, uint32_t len) {
 
 struct CanonArgs { BatchDev b; uint32_t mode; };
 
-__global__ __launch_bounds__(64) void canon_body_kernel(CanonArgs A) {
-  const BatchDev& B = A.b;
-  const uint32_t i = blockIdx.x;
-  if (i >= B.n) return;
+// Canonicalise the body of e-mail i with the calling wave.  `flags`, `boff`, `blen` and the l= value are handed
+// over in registers: the wave-per-e-mail front end calls this right after it has chosen the candidate signature
+// (no launch boundary, no trip through EmailMeta); the stand-alone kernel below reads them from EmailMeta.
+__device__ __forceinline__ void canon_body_wave(const BatchDev& B, uint32_t i, uint32_t mode, uint32_t flags, uint32_t boff,
+                                                uint32_t blen, uint64_t len_tag) {
   const int lane = lane_id();
   EmailMeta* M = B.meta + i;
-  if (M->state != ST_CAND) return;
-  if (A.mode == 1 && M->reuse) return;
   zke_result* R = B.results + i;
   const uint64_t r0 = B.raw_off[i];
   const uint32_t raw_len = (uint32_t)(B.raw_off[i + 1] - r0);
-  const uint32_t boff = M->body_off, blen = M->body_len;
   const uint8_t* body = B.raw + r0 + boff;
-  uint8_t* regB = B.scratch + B.scratch_off[i] + (((size_t)raw_len + PRE_SLACK + 15) & ~(size_t)15);
-  const uint32_t flags = M->flags;
+  uint8_t* regB = B.scratch + scratch_offset(r0 - B.raw_off[0], i) + (((size_t)raw_len + PRE_SLACK + 15) & ~(size_t)15);
   uint32_t full = 0, src_is_raw = 0;
 
   if (!(flags & ZKE_F_BODY_RELAXED)) {
@@ -128,18 +125,28 @@ __global__ __launch_bounds__(64) void canon_body_kernel(CanonArgs A) {
   }
   uint32_t hashed = full;
   if (flags & ZKE_F_HAS_LENGTH) {
-    const uint64_t lt = ((uint64_t)M->len_tag_hi << 32) | M->len_tag_lo;
-    if (lt < hashed) hashed = (uint32_t)lt;
+    if (len_tag < hashed) hashed = (uint32_t)len_tag;
   }
   if (lane == 0) {
     M->canon_full_len = full; M->hashed_len = hashed; M->body_src_is_raw = src_is_raw;
-    if (A.mode == 0) {
+    if (mode == 0) {
       R->canon_body_len = hashed;
       ShaJob j; j.src = (uint64_t)(src_is_raw ? body : regB); j.dst = (uint64_t)R->body_hash; j.len = hashed;
       j.pad = (flags & ZKE_F_SHA1) ? 1u : 0u;
       B.sha[i] = j;                             // kind 0
     }
   }
+}
+
+// stand-alone launch: the canonicalize_signed_email pass (mode 1) and the lane-per-e-mail front end
+__global__ __launch_bounds__(64) void canon_body_kernel(CanonArgs A) {
+  const BatchDev& B = A.b;
+  const uint32_t i = blockIdx.x;
+  if (i >= B.n) return;
+  const EmailMeta* M = B.meta + i;
+  if (M->state != ST_CAND) return;
+  if (A.mode == 1 && M->reuse) return;
+  canon_body_wave(B, i, A.mode, M->flags, M->body_off, M->body_len, ((uint64_t)M->len_tag_hi << 32) | M->len_tag_lo);
 }
 
 // ---- verdict of one signature round, by the wave that ran the e-mail's RSA job -----------------------

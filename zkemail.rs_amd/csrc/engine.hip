@@ -100,6 +100,7 @@ struct zke_engine {
   bool wave_parse = true;           // front end: one e-mail per wavefront (parse.hip.h); ZKE_LANE_PARSE=1 selects the
                                     // one-e-mail-per-lane variant (front.hip.h), see DESIGN.md §3
   uint32_t debug_skip_rsa = 0;      // ZKE_DEBUG_SKIP_RSA: ablation experiments (results are then meaningless)
+  uint32_t fuse_canon = 1;          // body canonicalisation inside the wave-per-e-mail front end (ZKE_NO_FUSE_CANON=1: own launch)
   uint32_t debug_skip_ed = 0;       // ZKE_DEBUG_SKIP_ED: ablation, drops the Ed25519 stage launch (Ed25519 e-mails then fail)
   uint32_t debug_parse_stop = 0;    // ZKE_DEBUG_PARSE_STOP: timing experiments (results are then meaningless)
   uint32_t max_sig_rounds = 4;      // host mode: upper bound, rounds are added only while e-mails are pending
@@ -196,6 +197,7 @@ int zke_engine_create(const zke_options* opt, zke_engine** out) {
   if (const char* st = getenv("ZKE_SHA_TILE")) e->sha_tile = atoi(st);
   if (getenv("ZKE_DEBUG_SKIP_RSA")) e->debug_skip_rsa = 1;
   if (getenv("ZKE_DEBUG_SKIP_ED")) e->debug_skip_ed = 1;
+  if (getenv("ZKE_NO_FUSE_CANON")) e->fuse_canon = 0;
   if (const char* ds = getenv("ZKE_DEBUG_PARSE_STOP")) e->debug_parse_stop = (uint32_t)atoi(ds);
   if (opt && opt->reserved[2]) e->use_graphs = true;           // reserved[2] != 0: experimental hipGraph replay
   *out = e;

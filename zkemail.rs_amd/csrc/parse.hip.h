@@ -583,7 +583,11 @@ __device__ __forceinline__ bool same_bytes(const Str& v, uint32_t p, uint32_t a,
 // ------------------------------------------------------------------ the parse kernel
 // mode 0: verify_email_with_key scan (round r picks the r-th same-domain candidate)
 // mode 1: canonicalize_signed_email (first DKIM-Signature header, no domain filter; core/src/circuits.rs:34-35)
-struct ParseArgs { BatchDev b; uint32_t round; uint32_t mode; uint32_t debug_stop; };   // debug_stop: timing experiments only (0 = off)
+struct ParseArgs { BatchDev b; uint32_t round; uint32_t mode; uint32_t debug_stop; uint32_t fuse_canon; };   // fuse_canon: canonicalise the body here (mode 0)
+
+// canon.hip.h
+__device__ __forceinline__ void canon_body_wave(const BatchDev& B, uint32_t i, uint32_t mode, uint32_t flags, uint32_t boff,
+                                                uint32_t blen, uint64_t len_tag);   // debug_stop: timing experiments only (0 = off)
 
 __device__ const uint8_t DKIM_NAME[14] = {'D', 'K', 'I', 'M', '-', 'S', 'i', 'g', 'n', 'a', 't', 'u', 'r', 'e'};
 
@@ -702,6 +706,8 @@ __global__ __launch_bounds__(64) void parse_kernel(ParseArgs A) {
   uint32_t err_after = 0;      // last non-candidate error after this round's candidate
   bool have_cand = false;
   uint32_t first_sig_hdr = NONE;
+  uint32_t cand_flags = 0;
+  uint64_t cand_len_tag = 0;
   for (uint32_t hx = 0; hx < nh; hx++) {
     const uint32_t ks = L.hdr[4 * hx], ke = L.hdr[4 * hx + 1], vs = L.hdr[4 * hx + 2], ve = L.hdr[4 * hx + 3];
     if (!span_ieq(raw, ks, ke - ks, DKIM_NAME, 14)) continue;
@@ -879,6 +885,7 @@ __global__ __launch_bounds__(64) void parse_kernel(ParseArgs A) {
       have_cand = false; cand_count--;
       continue;
     }
+    cand_flags = flags; cand_len_tag = len_tag;
     if (lane == 0) {
       M->cand_sig_index = this_ix; M->cand_hdr = hx; M->flags = flags;
       M->len_tag_lo = (uint32_t)len_tag; M->len_tag_hi = (uint32_t)(len_tag >> 32);
@@ -908,8 +915,10 @@ __global__ __launch_bounds__(64) void parse_kernel(ParseArgs A) {
   if (lane == 0) {
     M->state = ST_CAND;
     // an Ed25519 candidate leaves the RSA job inactive; ed25519_email_kernel verifies it
-    J->flags = (M->flags & ZKE_F_ED25519) ? 0u : (RSA_F_ACTIVE | ((M->flags & ZKE_F_SHA1) ? (uint32_t)RSA_F_SHA1 : 0u));
+    J->flags = (cand_flags & ZKE_F_ED25519) ? 0u : (RSA_F_ACTIVE | ((cand_flags & ZKE_F_SHA1) ? (uint32_t)RSA_F_SHA1 : 0u));
   }
+  // ---- body canonicalisation of the candidate (cfdkim hash::compute_body_hash), same wave, no launch boundary
+  if (A.fuse_canon) canon_body_wave(B, i, 0, cand_flags, body_off, raw.len - body_off, cand_len_tag);
 }
 
 // CSR (blob, off[n+1]) -> ShaJob list with digests packed 32 B apart (building-block entry point)

@@ -69,15 +69,17 @@ int run_device_pipeline(zke_engine* e, const zke_batch* in, uint64_t raw_total, 
   const uint32_t rounds = max_rounds;
   for (uint32_t round = round_begin; round < round_end; round++) {
     if (e->wave_parse) {
-      ParseArgs pa{B, round, 0, e->debug_parse_stop};
+      ParseArgs pa{B, round, 0, e->debug_parse_stop, e->fuse_canon};
       hipLaunchKernelGGL(parse_kernel, dim3(n), dim3(64), 0, s, pa);
     } else {
       FrontArgs fa{B, e->lanews.as<LaneWs>(), round, 0, e->debug_parse_stop};
       hipLaunchKernelGGL(front_kernel, dim3((n + 63) / 64), dim3(64), FRONT_LDS_BYTES, s, fa);
     }
     if (round == 0) tm.mark();
-    CanonArgs ca{B, 0};
-    hipLaunchKernelGGL(canon_body_kernel, dim3(n), dim3(64), 0, s, ca);
+    if (!(e->wave_parse && e->fuse_canon)) {      // the wave-per-e-mail front end canonicalises the body itself
+      CanonArgs ca{B, 0};
+      hipLaunchKernelGGL(canon_body_kernel, dim3(n), dim3(64), 0, s, ca);
+    }
     if (round == 0) tm.mark();
     if ((r = launch_sha_any(e, B.sha, 4 * n_pad, s))) return r;
     if (round == 0) tm.mark();
@@ -101,7 +103,7 @@ int run_device_pipeline(zke_engine* e, const zke_batch* in, uint64_t raw_total, 
     B2.scratch = e->scratch2.as<uint8_t>();
     B2.meta_verify = B.meta;
     if (e->wave_parse) {
-      ParseArgs pa{B2, 0, 1, 0};
+      ParseArgs pa{B2, 0, 1, 0, 0};
       hipLaunchKernelGGL(parse_kernel, dim3(n), dim3(64), 0, s, pa);
     } else {
       FrontArgs fa{B2, e->lanews.as<LaneWs>(), 0, 1, 0};
