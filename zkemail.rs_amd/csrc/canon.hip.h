@@ -43,8 +43,10 @@ struct CanonArgs { BatchDev b; uint32_t mode; };
 // Canonicalise the body of e-mail i with the calling wave.  `flags`, `boff`, `blen` and the l= value are handed
 // over in registers: the wave-per-e-mail front end calls this right after it has chosen the candidate signature
 // (no launch boundary, no trip through EmailMeta); the stand-alone kernel below reads them from EmailMeta.
+// `lds`: CANON_LDS_BYTES of 16-byte aligned LDS the wave may overwrite (the front end hands over its staging buffer).
+constexpr uint32_t CANON_LDS_TRASH = 2048, CANON_LDS_BYTES = 2048 + 64;
 __device__ __forceinline__ void canon_body_wave(const BatchDev& B, uint32_t i, uint32_t mode, uint32_t flags, uint32_t boff,
-                                                uint32_t blen, uint64_t len_tag) {
+                                                uint32_t blen, uint64_t len_tag, uint8_t* lds) {
   const int lane = lane_id();
   EmailMeta* M = B.meta + i;
   zke_result* R = B.results + i;
@@ -64,55 +66,88 @@ __device__ __forceinline__ void canon_body_wave(const BatchDev& B, uint32_t i, u
       src_is_raw = 1;
     }
   } else {
-    // 4 consecutive bytes per lane, 256 B per step; the next step's dword is loaded one step ahead.
+    // 4 consecutive bytes per lane, 256 B per step.  Loads run four steps (1 KB) ahead of their use, so a step
+    // never waits for HBM; output bytes are compacted into LDS and leave in 16-byte lane-contiguous stores every
+    // four steps instead of eight predicated byte stores per step.
     typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+    typedef uint4 __attribute__((aligned(1))) uint4_store_unaligned;
     auto load4 = [&](uint32_t pos) -> uint32_t {       // bytes pos..pos+3 of the body, zero beyond the end
       if (pos + 4 <= blen) return *(const u32_unaligned*)(body + pos);
       uint32_t v = 0;
       for (uint32_t t = 0; t < 4; t++) if (pos + t < blen) v |= (uint32_t)body[pos + t] << (8 * t);
       return v;
     };
-    uint32_t o = 0;
-    uint32_t cur = load4(4 * lane);
+    uint32_t o = 0;                           // bytes already in regB
+    uint32_t q[4];                            // the next four 256-byte windows, one dword per lane each
+#pragma unroll
+    for (int k = 0; k < 4; k++) q[k] = load4(256u * k + 4 * lane);
     uint32_t prev_last = OOB;                 // byte before this step's 256-byte window
-    for (uint32_t base = 0; base < blen; base += 256) {
-      const uint32_t nxt = load4(base + 256 + 4 * lane);          // in flight while this window is processed
-      const uint32_t pos0 = base + 4 * lane;
-      uint32_t pv = lane_down(cur >> 24); if (lane == 0) pv = prev_last;       // byte in front of my 4
-      uint32_t nb = lane_up(cur & 0xff);                                          // byte after my 4
-      const uint32_t nfirst = __builtin_amdgcn_readfirstlane(nxt) & 0xff;
-      if (lane == 63) nb = (base + 256 < blen) ? nfirst : OOB;
-      uint32_t outb[8];
-      uint32_t cnt = 0;
-      bool pw = is_wsp(pv);
+    for (uint32_t base0 = 0; base0 < blen; base0 += 1024) {
+      uint32_t fill = 0;                      // bytes compacted into LDS by this group of steps (<= 4 * 512)
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const uint32_t c = (cur >> (8 * j)) & 0xff;
-        const uint32_t n = (j < 3) ? ((cur >> (8 * (j + 1))) & 0xff) : nb;
-        const bool inr = pos0 + j < blen;
-        const bool nin = pos0 + j + 1 < blen;
-        const bool w = is_wsp(c);
-        const bool k = inr && !w;
-        const bool sp = k && pw && !(c == '\r' && nin && n == '\n');
-        if (sp) { outb[cnt] = ' '; cnt++; }
-        if (k) { outb[cnt] = c; cnt++; }
-        pw = inr ? w : pw;
+      for (int k = 0; k < 4; k++) {
+        const uint32_t base = base0 + 256u * k;
+        if (base < blen) {                    // wave-uniform
+          const uint32_t cur = q[k];
+          q[k] = load4(base + 1024 + 4 * lane);                                    // four steps ahead
+          const uint32_t nxtw = q[(k + 1) & 3];                                    // the window after this one
+          const uint32_t pos0 = base + 4 * lane;
+          uint32_t pv = lane_down(cur >> 24); if (lane == 0) pv = prev_last;       // byte in front of my 4
+          uint32_t nb = lane_up(cur & 0xff);                                        // byte after my 4
+          const uint32_t nfirst = __builtin_amdgcn_readfirstlane(nxtw) & 0xff;
+          if (lane == 63) nb = (base + 256 < blen) ? nfirst : OOB;
+          // up to 8 output bytes of this lane, appended into a 64-bit shift register (no indexed register array)
+          uint64_t out64 = 0;
+          uint32_t sh = 0;                    // 8 * bytes appended
+          bool pw = is_wsp(pv);
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const uint32_t c = (cur >> (8 * j)) & 0xff;
+            const uint32_t n = (j < 3) ? ((cur >> (8 * (j + 1))) & 0xff) : nb;
+            const bool inr = pos0 + j < blen;
+            const bool nin = pos0 + j + 1 < blen;
+            const bool w = is_wsp(c);
+            const bool kp = inr && !w;
+            const bool sp = kp && pw && !(c == '\r' && nin && n == '\n');
+            // "SP c" (two bytes), "c" (one) or nothing
+            const uint32_t piece = sp ? (0x20u | (c << 8)) : c;
+            const uint32_t plen = kp ? (sp ? 16u : 8u) : 0u;
+            out64 |= (uint64_t)(kp ? piece : 0u) << sh;
+            sh += plen;
+            pw = inr ? w : pw;
+          }
+          const uint32_t cnt = sh >> 3;
+          // exclusive prefix of cnt (0..8) over the lanes: one ballot per bit of the count
+          const uint64_t below = bits_below(lane);
+          uint32_t off = 0, total = 0;
+#pragma unroll
+          for (int bit = 0; bit < 4; bit++) {
+            const uint64_t m = __ballot((cnt >> bit) & 1);
+            off += (uint32_t)__builtin_popcountll(m & below) << bit;
+            total += (uint32_t)__builtin_popcountll(m) << bit;
+          }
+          // byte t of the lane goes to its place, or to a per-lane trash byte behind the staging area when t >= cnt
+          // (an unconditional store with a selected address is cheaper than eight exec-masked ones)
+#pragma unroll
+          for (int t = 0; t < 8; t++) {
+            const uint32_t at = (uint32_t)t < cnt ? fill + off + t : CANON_LDS_TRASH + (uint32_t)lane;
+            lds[at] = (uint8_t)(out64 >> (8 * t));
+          }
+          fill += total;
+          prev_last = __builtin_amdgcn_readlane(cur, 63) >> 24;
+        }
       }
-      // exclusive prefix of cnt (0..8) over the lanes: one ballot per bit of the count
-      const uint64_t below = bits_below(lane);
-      uint32_t off = 0, total = 0;
-#pragma unroll
-      for (int bit = 0; bit < 4; bit++) {
-        const uint64_t m = __ballot((cnt >> bit) & 1);
-        off += (uint32_t)__builtin_popcountll(m & below) << bit;
-        total += (uint32_t)__builtin_popcountll(m) << bit;
+      // flush the group: 16 bytes per lane and store, then the (< 16) byte tail
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      for (uint32_t bq = 16u * lane; bq + 16 <= fill; bq += 1024) *(uint4_store_unaligned*)(regB + o + bq) = *(const uint4*)(lds + bq);
+      {
+        const uint32_t tb = (fill & ~15u) + lane;
+        if (lane < 16 && tb < fill) regB[o + tb] = lds[tb];
       }
-#pragma unroll
-      for (int t = 0; t < 8; t++) if ((uint32_t)t < cnt) regB[o + off + t] = (uint8_t)outb[t];
-      o += total;
-      const uint32_t lastlane = __builtin_amdgcn_readlane(cur, 63);
-      prev_last = lastlane >> 24;
-      cur = nxt;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      o += fill;
     }
     // a WSP run that ends the body is not followed by CRLF: its single SP stays
     if (blen && is_wsp((uint32_t)body[blen - 1])) { if (lane == 0) regB[o] = ' '; o++; }
@@ -146,7 +181,8 @@ __global__ __launch_bounds__(64) void canon_body_kernel(CanonArgs A) {
   const EmailMeta* M = B.meta + i;
   if (M->state != ST_CAND) return;
   if (A.mode == 1 && M->reuse) return;
-  canon_body_wave(B, i, A.mode, M->flags, M->body_off, M->body_len, ((uint64_t)M->len_tag_hi << 32) | M->len_tag_lo);
+  __shared__ __attribute__((aligned(16))) uint8_t canon_lds[CANON_LDS_BYTES];
+  canon_body_wave(B, i, A.mode, M->flags, M->body_off, M->body_len, ((uint64_t)M->len_tag_hi << 32) | M->len_tag_lo, canon_lds);
 }
 
 // ---- verdict of one signature round, by the wave that ran the e-mail's RSA job -----------------------

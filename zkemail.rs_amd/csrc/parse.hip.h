@@ -587,7 +587,7 @@ struct ParseArgs { BatchDev b; uint32_t round; uint32_t mode; uint32_t debug_sto
 
 // canon.hip.h
 __device__ __forceinline__ void canon_body_wave(const BatchDev& B, uint32_t i, uint32_t mode, uint32_t flags, uint32_t boff,
-                                                uint32_t blen, uint64_t len_tag);   // debug_stop: timing experiments only (0 = off)
+                                                uint32_t blen, uint64_t len_tag, uint8_t* lds);   // debug_stop: timing experiments only (0 = off)
 
 __device__ const uint8_t DKIM_NAME[14] = {'D', 'K', 'I', 'M', '-', 'S', 'i', 'g', 'n', 'a', 't', 'u', 'r', 'e'};
 
@@ -918,7 +918,7 @@ __global__ __launch_bounds__(64) void parse_kernel(ParseArgs A) {
     J->flags = (cand_flags & ZKE_F_ED25519) ? 0u : (RSA_F_ACTIVE | ((cand_flags & ZKE_F_SHA1) ? (uint32_t)RSA_F_SHA1 : 0u));
   }
   // ---- body canonicalisation of the candidate (cfdkim hash::compute_body_hash), same wave, no launch boundary
-  if (A.fuse_canon) canon_body_wave(B, i, 0, cand_flags, body_off, raw.len - body_off, cand_len_tag);
+  if (A.fuse_canon) canon_body_wave(B, i, 0, cand_flags, body_off, raw.len - body_off, cand_len_tag, L.stage);   // parsing is over: the staged head is dead
 }
 
 // CSR (blob, off[n+1]) -> ShaJob list with digests packed 32 B apart (building-block entry point)
