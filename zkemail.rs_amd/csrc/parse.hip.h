@@ -114,7 +114,7 @@ __device__ __forceinline__ void batch_prologue(const BatchDev& B, uint32_t i, bo
     }
   }
 }
-constexpr uint32_t PARSE_STAGE_BYTES = 4096;   // header blocks beyond this are read from HBM past the staged part
+constexpr uint32_t PARSE_STAGE_BYTES = 3840;   // header blocks beyond this are read from HBM past the staged part
 
 // ------------------------------------------------------------------ byte strings and windows
 struct Str {                  // logical string over global memory with one optional excision
@@ -194,6 +194,10 @@ __device__ __forceinline__ bool span_ieq(const Str& s, uint32_t a, uint32_t n, c
   return true;
 }
 
+// value of the neighbouring lane (0 beyond the wave): DPP wave shifts
+__device__ __forceinline__ uint32_t lane_shl1(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130 /*wave_shl:1: lane l <- l+1*/, 0xf, 0xf, false); }
+__device__ __forceinline__ uint32_t lane_shr1(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138 /*wave_shr:1: lane l <- l-1*/, 0xf, 0xf, false); }
+
 // ------------------------------------------------------------------ output stream (preimage)
 struct Out { uint8_t* p; uint32_t o, cap; bool overflow; };
 __device__ __forceinline__ void emit_lit(Out& out, const char* lit, uint32_t n) {
@@ -209,44 +213,46 @@ __device__ __forceinline__ void emit_map(Out& out, const Str& s, uint32_t a, uin
   out.o += b - a;
 }
 
-// cfdkim canonicalize_header_relaxed value part: unfold (drop CRLF), WSP runs -> one SP, trim both ends
+// cfdkim canonicalize_header_relaxed value part: unfold (drop CRLF), WSP runs -> one SP, trim both ends.
+// One forward pass, one load per lane and 64-byte chunk (issued a chunk ahead; the neighbours come over DPP):
+// a WSP run becomes the single SP written IN FRONT OF the next kept non-WSP byte, so leading runs (nothing
+// emitted yet) and trailing runs (no such byte) vanish without a backward scan for the last kept byte.
 __device__ __forceinline__ void emit_relaxed_value(Out& out, const Str& v) {
   const uint32_t L = v.len;
-  // last kept non-WSP byte
-  uint32_t last_nw = NONE;
-  for (uint32_t hi = L; hi > 0 && last_nw == NONE;) {
-    const uint32_t lo = hi > 64 ? hi - 64 : 0;
-    const uint32_t l = lo + lane_id();
-    bool k = false;
-    if (l < hi) {
-      const uint32_t cc = ldb(v, l), cp = l ? ldb(v, l - 1) : OOB, cn = ldb(v, l + 1);
-      const bool crlf = (cc == '\r' && cn == '\n') || (cc == '\n' && cp == '\r');
-      k = !crlf && !is_wsp(cc);
-    }
-    const uint64_t m = __ballot(k);
-    if (m) last_nw = lo + 63u - (uint32_t)__builtin_clzll(m);
-    hi = lo;
-  }
-  if (last_nw == NONE) return;
-  bool carry_wsp = true;     // "previous kept byte was WSP": true at the start trims the front
-  for (uint32_t base = 0; base <= last_nw; base += 64) {
-    const uint32_t l = base + lane_id();
-    const uint32_t cc = ldb(v, l), cp = l ? ldb(v, l - 1) : OOB, cn = ldb(v, l + 1);
-    const bool inr = l <= last_nw;
-    const bool crlf = (cc == '\r' && cn == '\n') || (cc == '\n' && cp == '\r');
-    const bool kept1 = inr && !crlf;
-    const bool wsp = is_wsp(cc);
-    const uint64_t K1 = __ballot(kept1), Wm = __ballot(kept1 && wsp);
-    const uint64_t lowerK = K1 & bits_below(lane_id());
-    bool prevw = carry_wsp;
-    if (lowerK) prevw = (Wm >> (63 - __builtin_clzll(lowerK))) & 1;
-    const bool emit = kept1 && (!wsp || !prevw);
-    const uint64_t E = __ballot(emit);
-    const uint32_t cnt = (uint32_t)__builtin_popcountll(E);
+  if (L == 0) return;
+  const int lane = lane_id();
+  bool prev_wsp = false;       // the last kept byte before this chunk is WSP
+  bool started = false;        // a non-WSP byte has been emitted
+  uint32_t prev_last = OOB;    // raw byte in front of this chunk
+  uint32_t cur = ldb(v, (uint32_t)lane);
+  for (uint32_t base = 0; base < L; base += 64) {
+    const uint32_t nxt = ldb(v, base + 64 + lane);                 // next chunk, in flight during this one
+    const uint32_t l = base + lane;
+    uint32_t cp = lane_shr1(cur); if (lane == 0) cp = prev_last;
+    uint32_t cn = lane_shl1(cur); if (lane == 63) cn = __builtin_amdgcn_readfirstlane(nxt);
+    const bool inr = l < L;
+    const bool crlf = (cur == '\r' && cn == '\n') || (cur == '\n' && cp == '\r');
+    const bool kept = inr && !crlf;
+    const bool wsp = is_wsp(cur);
+    const bool nw = kept && !wsp;
+    const uint64_t K = __ballot(kept), W = __ballot(kept && wsp), N = __ballot(nw);
+    const uint64_t below = bits_below(lane);
+    bool prevw = prev_wsp;
+    const uint64_t lowerK = K & below;
+    if (lowerK) prevw = (W >> (63 - __builtin_clzll(lowerK))) & 1;
+    const bool sp = nw && prevw && (started || (N & below) != 0);
+    const uint64_t S = __ballot(sp);
+    const uint32_t cnt = (uint32_t)__builtin_popcountll(N) + (uint32_t)__builtin_popcountll(S);
     if (out.o + cnt > out.cap) { out.overflow = true; return; }
-    if (emit) out.p[out.o + (uint32_t)__builtin_popcountll(E & bits_below(lane_id()))] = wsp ? (uint8_t)' ' : (uint8_t)cc;
+    if (nw) {
+      uint8_t* dst = out.p + out.o + (uint32_t)__builtin_popcountll(N & below) + (uint32_t)__builtin_popcountll(S & below);
+      if (sp) { dst[0] = (uint8_t)' '; dst[1] = (uint8_t)cur; } else dst[0] = (uint8_t)cur;
+    }
     out.o += cnt;
-    if (K1) carry_wsp = (Wm >> (63 - __builtin_clzll(K1))) & 1;
+    if (K) prev_wsp = (W >> (63 - __builtin_clzll(K))) & 1;
+    started = started || N != 0;
+    prev_last = __builtin_amdgcn_readlane(cur, 63);
+    cur = nxt;
   }
 }
 
@@ -591,7 +597,7 @@ __device__ __forceinline__ void canon_body_wave(const BatchDev& B, uint32_t i, u
 
 __device__ const uint8_t DKIM_NAME[14] = {'D', 'K', 'I', 'M', '-', 'S', 'i', 'g', 'n', 'a', 't', 'u', 'r', 'e'};
 
-__global__ __launch_bounds__(64) void parse_kernel(ParseArgs A) {
+__global__ __launch_bounds__(64, 4) void parse_kernel(ParseArgs A) {
   __shared__ ParseLds L;
   const BatchDev& B = A.b;
   const uint32_t i = blockIdx.x;
