@@ -124,11 +124,60 @@ __device__ __forceinline__ uint32_t big_normalize(Big<NL>& r, const uint32_t (&l
   return cin + cbit;
 }
 
+// The 64 CIOS steps of a one-limb-per-lane Montgomery product, written out by hand (gfx950), vector unit only
+// (the scalar unit is shared by the four SIMDs of a CU: one s_add per step is all it sees).
+// Column state per lane: T = tl + th * 2^32 in a VGPR pair = the 64-bit addend of the first multiply.
+//   P = a * b_i + T                 v_mad_u64_u32, carry-out c0 (65th bit; only when a = b_i = 2^32 - 1)
+//   m = lo(P of lane 0) * ninv      v_mul_lo_u32 + v_readfirstlane
+//   Q = n * m + P                   v_mad_u64_u32, carry-out c1
+//   tl' = hi(Q) + lo(Q of lane+1)   one v_add_co_u32 with the DPP wave shift folded in, carry c2
+//   th' = c2 + c0 + c1              three v_addc_co_u32
+// 9 VALU instructions per step against 16 (seven of them register-pair moves) from the C++ below.
+// Fixed temporaries v[76:83], s[60:67] (clobbers).  Wait states (gfx940 rules): one between a VALU write and a
+// v_readfirstlane of the register, two before a DPP read.
+__device__ __forceinline__ void mont_core_64(uint32_t& tl, uint32_t& th, uint32_t a, uint32_t b, uint32_t n, uint32_t ninv) {
+  asm volatile(
+      "v_mov_b32 v76, 0\n\t"
+      "v_mov_b32 v77, 0\n\t"
+      "v_mov_b32 v82, 0\n\t"
+      "s_mov_b32 s60, 0\n\t"
+      "v_readlane_b32 s61, %3, s60\n"              // b_0
+      "1:\n\t"
+      ".rept 4\n\t"
+      "v_mad_u64_u32 v[78:79], s[64:65], %2, s61, v[76:77]\n\t"
+      "v_mul_lo_u32 v83, v78, %5\n\t"
+      "s_add_u32 s60, s60, 1\n\t"
+      "v_readfirstlane_b32 s62, v83\n\t"
+      "v_mad_u64_u32 v[80:81], s[66:67], %4, s62, v[78:79]\n\t"
+      "v_readlane_b32 s61, %3, s60\n\t"           // next b limb (lane select 64 after the last step reads lane 0: unused)
+      "v_addc_co_u32_e64 v77, s[62:63], v82, 0, s[64:65]\n\t"       // th' = c0
+      "v_add_co_u32_dpp v76, vcc, v80, v81 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "v_addc_co_u32_e32 v77, vcc, 0, v77, vcc\n\t"                  // + c2
+      "v_addc_co_u32_e64 v77, s[62:63], v77, 0, s[66:67]\n\t"       // + c1
+      ".endr\n\t"
+      "s_cmp_lt_u32 s60, 64\n\t"
+      "s_cbranch_scc1 1b\n\t"
+      "v_mov_b32 %0, v76\n\t"
+      "v_mov_b32 %1, v77"
+      : "=&v"(tl), "=&v"(th)
+      : "v"(a), "v"(b), "v"(n), "s"(__builtin_amdgcn_readfirstlane(ninv))
+      : "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "vcc", "scc");
+}
+
 // Montgomery product r = a*b*R^-1 mod n, R = 2^(2048*NL); a, b < n; n odd; ninv = -n^-1 mod 2^32.
 template <int NL>
 __device__ __forceinline__ void mont_mul(Big<NL>& r, const Big<NL>& a, const Big<NL>& b, const Big<NL>& n,
                                          uint32_t ninv, int lane) {
   uint32_t tl[NL], th[NL];
+#ifndef ZKE_MONT_CXX
+  if constexpr (NL == 1) {
+    mont_core_64(tl[0], th[0], a.v[0], b.v[0], n.v[0], ninv);
+    Big<NL> t1;
+    const uint32_t top1 = big_normalize<NL>(t1, tl, th, lane);
+    if (top1 || big_ge<NL>(t1, n)) big_sub<NL>(r, t1, n, lane); else r = t1;
+    return;
+  }
+#endif
 #pragma unroll
   for (int q = 0; q < NL; q++) { tl[q] = 0; th[q] = 0; }
 #pragma unroll 1
