@@ -250,6 +250,26 @@ def _two_sigs(first_broken: bool = False) -> Case:
     return Case(name, Email("example.com", other_sig_hdr + raw, PublicKey(k0.pkcs1_der)), A.ZKE_OK, None, inter)
 
 
+def fold_offset_emails():
+    """Header values whose folding CRLF, WSP runs and end fall on every offset modulo 64 (the device scans header
+    values 64 bytes per step), for both header canonicalisations; signed by the Python signer.
+    -> (emails, intermediates)"""
+    k0 = K()
+    emails, inter = [], []
+    for off in range(0, 140):
+        subj = b"s" * off + b"\r\n \t folded  part" + b" " * (off % 5) + b"\r\n\tend" + b"e" * (off % 7)
+        to = b"t" * (off % 67) + b" \t " + b"u" * ((3 * off) % 61) + b" "
+        hs = [(b"From", b"a@example.com"), (b"To", to), (b"Subject", subj), (b"Date", b"Tue, 03 Oct 2026 10:00:00 +0000"),
+              (b"Message-ID", b"<%d@example.com>" % off)]
+        for hc in ("relaxed", "simple"):
+            if hc == "simple" and (to.startswith(b" ") or subj.startswith(b" ")):
+                continue        # cfdkim's simple header rebuild drops leading WSP (quirk case above)
+            raw, it = sign_email(hs, _body(200, off), k0, SignSpec(header_canon=hc))
+            emails.append(Email("example.com", raw, PublicKey(k0.pkcs1_der)))
+            inter.append(it)
+    return emails, inter
+
+
 def expected_witness(c: Case):
     return (hashlib.sha256(c.email.from_domain.encode()).digest(), hashlib.sha256(c.email.public_key.key).digest())
 

@@ -68,6 +68,16 @@ def test_workload_shapes(oracle):
     assert (r["status"] == 0).all() and (r["rsa_bits"] == 4096).all()
 
 
+def test_header_folds_at_every_chunk_offset(oracle):
+    emails, inter = cases.fold_offset_emails()
+    dbg = A.DebugBuffers(len(emails), 4096, 1024)
+    r = oracle.verify_batch(A.PackedBatch(emails), dbg, threads=4)
+    assert (r["status"] == 0).all()
+    for i, it in enumerate(inter):
+        assert bytes(dbg.canon_header[i, :len(it["canon_header"])]) == it["canon_header"]
+        assert bytes(r[i]["header_hash"]) == it["header_hash"]
+
+
 def test_mailparse_header_split(oracle):
     raw = (b"A: 1\r\nB:  two\r\n folded\r\nC:\r\nD\r\nE : spaced key\r\nF:\tTabbed\r\nG: x\ny\r\n\r\nbody")
     n, hs, body_ix = oracle.parse_headers(raw)

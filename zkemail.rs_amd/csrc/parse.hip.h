@@ -229,7 +229,8 @@ __device__ __forceinline__ void emit_relaxed_value(Out& out, const Str& v) {
     const uint32_t nxt = ldb(v, base + 64 + lane);                 // next chunk, in flight during this one
     const uint32_t l = base + lane;
     uint32_t cp = lane_shr1(cur); if (lane == 0) cp = prev_last;
-    uint32_t cn = lane_shl1(cur); if (lane == 63) cn = __builtin_amdgcn_readfirstlane(nxt);
+    const uint32_t nfirst = __builtin_amdgcn_readfirstlane(nxt);     // outside the lane test: all lanes active here
+    uint32_t cn = lane_shl1(cur); if (lane == 63) cn = nfirst;
     const bool inr = l < L;
     const bool crlf = (cur == '\r' && cn == '\n') || (cur == '\n' && cp == '\r');
     const bool kept = inr && !crlf;
