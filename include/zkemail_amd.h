@@ -91,7 +91,7 @@ enum {
   /* ZKE_UNSUPPORTED, continued */
   ZKE_D_U_SIG_TOO_LONG       = 63, /* FWS-stripped tag values of one DKIM-Signature exceed ZKE_MAX_TAGBUF bytes */
   ZKE_D_U_TOO_MANY_SIGS      = 64, /* more failing same-domain signatures than the engine's signature rounds */
-  ZKE_D_U_SIG_B_REPEATED     = 65  /* the raw b= value occurs more than once in its header (reference removes every occurrence) */
+  ZKE_D_U_SIG_B_REPEATED     = 65  /* (no longer produced: both front ends remove every occurrence of the raw b= value, as the reference does) */
 };
 
 #define ZKE_MAX_HEADERS 256u   /* header fields per email the device parser tables hold */

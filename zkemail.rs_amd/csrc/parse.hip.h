@@ -807,29 +807,45 @@ __global__ __launch_bounds__(64, 4) void parse_kernel(ParseArgs A) {
       }
       for (uint32_t o = lane; o < 48; o += 64) M->bh[o] = o < L.tag[TG_BH][3] ? L.tagbuf[L.tag[TG_BH][2] + o] : 0;
     }
-    // String::replace removes every occurrence of the raw b= value; the device removes the tag's own span
-    // and reports any second occurrence instead of guessing
+    // String::replace removes EVERY occurrence of the raw b= value (leftmost first, non-overlapping).  Normally the
+    // tag's own span is the only one and the header is read through a one-excision view; when the value occurs
+    // again (only short, hand-made b= values do) the excised header is written out once to region B of the scratch
+    // slot — free until the body is canonicalised — and read back from there.
     const uint32_t bl = b_re - b_rs;
+    Str sv = v;
     if (bl) {
-      Win w; w.wpos = WNONE; w.c = 0;
       const uint32_t fl = bl < 8 ? bl : 8;
-      bool repeated = false;
-      for (uint32_t base = 0; base + bl <= v.len && !repeated; base += 64) {
-        const uint32_t p = base + lane;
-        bool cand = p + bl <= v.len && p != b_rs;
-        for (uint32_t t = 0; t < fl && cand; t++) cand = ldb(v, p + t) == ldb(v, b_rs + t);
-        uint64_t m = __ballot(cand);
-        while (m && !repeated) {
-          const uint32_t q = base + (uint32_t)__builtin_ctzll(m);
-          m &= m - 1;
-          if (same_bytes(v, q, b_rs, bl)) repeated = true;
+      auto next_occurrence = [&](uint32_t from, uint32_t skip_at) -> uint32_t {      // first match at >= from, != skip_at
+        for (uint32_t base = from; base + bl <= v.len; base += 64) {
+          const uint32_t p = base + lane;
+          bool cand = p + bl <= v.len && p != skip_at;
+          for (uint32_t t = 0; t < fl && cand; t++) cand = ldb(v, p + t) == ldb(v, b_rs + t);
+          uint64_t m = __ballot(cand);
+          while (m) {
+            const uint32_t q = base + (uint32_t)__builtin_ctzll(m);
+            m &= m - 1;
+            if (same_bytes(v, q, b_rs, bl)) return q;
+          }
         }
-      }
-      if (repeated) {
-        unsupported = ZKE_D_U_SIG_B_REPEATED;
-        if (A.mode == 1) { finish(ZKE_UNSUPPORTED, unsupported); return; }
-        have_cand = false; cand_count--;      // not hashable on the device: treated like an unsupported signature
-        continue;
+        return NONE;
+      };
+      if (next_occurrence(0, b_rs) == NONE) {
+        sv.len = v.len - bl; sv.cut = b_rs; sv.skip = bl;
+      } else {
+        uint8_t* tmp = regA + (((size_t)raw.len + PRE_SLACK + 15) & ~(size_t)15);    // region B: raw.len + 16 bytes
+        uint32_t pos = 0, tn = 0;
+        while (pos < v.len) {
+          const uint32_t q = next_occurrence(pos, NONE);
+          const uint32_t end = (q == NONE) ? v.len : q;
+          for (uint32_t l = pos + lane; l < end; l += 64) tmp[tn + (l - pos)] = (uint8_t)ldb(v, l);
+          tn += end - pos;
+          if (q == NONE) break;
+          pos = q + bl;
+        }
+        // the wave reads these bytes back with ordinary loads: make them visible past this CU's L1
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        sv = mkstr(tmp, tn);
       }
     }
     if (A.debug_stop == 6) return;
@@ -881,11 +897,7 @@ __global__ __launch_bounds__(64, 4) void parse_kernel(ParseArgs A) {
         st = e + 1;
       }
     }
-    {
-      Str sv = v;
-      if (bl) { sv.len = v.len - bl; sv.cut = b_rs; sv.skip = bl; }
-      emit_header(out, mkstr(DKIM_NAME, 14), sv, hrel, false);
-    }
+    emit_header(out, mkstr(DKIM_NAME, 14), sv, hrel, false);
     if (out.overflow) {
       unsupported = ZKE_D_U_PREIMAGE_OVERFLOW;
       if (A.mode == 1) { finish(ZKE_UNSUPPORTED, unsupported); return; }
