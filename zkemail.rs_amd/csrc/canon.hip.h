@@ -19,9 +19,11 @@ __device__ __forceinline__ uint32_t ld_coherent_u8(const uint8_t* p) {
 }
 
 // number of complete trailing CRLF pairs of a byte string of length len
+// (*ended: a byte that breaks the run was seen, i.e. the run does not reach the start of the range)
 template <class LD>
-__device__ __forceinline__ uint32_t trailing_crlf_pairs(LD load, uint32_t len) {
+__device__ __forceinline__ uint32_t trailing_crlf_pairs(LD load, uint32_t len, bool* ended = nullptr) {
   uint32_t matched = 0, pos = len;
+  if (ended) *ended = false;
   while (pos > 0) {
     const uint32_t lo = pos > 64 ? pos - 64 : 0;
     const uint32_t l = lo + lane_id();
@@ -31,7 +33,7 @@ __device__ __forceinline__ uint32_t trailing_crlf_pairs(LD load, uint32_t len) {
       bad = c != (((len - 1 - l) & 1) ? (uint32_t)'\r' : (uint32_t)'\n');
     }
     const uint64_t m = __ballot(bad);
-    if (m) { matched += (pos - 1) - (lo + 63u - (uint32_t)__builtin_clzll(m)); break; }
+    if (m) { matched += (pos - 1) - (lo + 63u - (uint32_t)__builtin_clzll(m)); if (ended) *ended = true; break; }
     matched += pos - lo;
     pos = lo;
   }
@@ -44,7 +46,8 @@ struct CanonArgs { BatchDev b; uint32_t mode; };
 // over in registers: the wave-per-e-mail front end calls this right after it has chosen the candidate signature
 // (no launch boundary, no trip through EmailMeta); the stand-alone kernel below reads them from EmailMeta.
 // `lds`: CANON_LDS_BYTES of 16-byte aligned LDS the wave may overwrite (the front end hands over its staging buffer).
-constexpr uint32_t CANON_LDS_TRASH = 2048, CANON_LDS_BYTES = 2048 + 64;
+constexpr uint32_t CANON_LDS_TRASH = 3776, CANON_LDS_BYTES = 3776 + 64;
+static_assert(CANON_LDS_BYTES <= PARSE_STAGE_BYTES, "the front end lends its staging buffer to the canonicaliser");
 __device__ __forceinline__ void canon_body_wave(const BatchDev& B, uint32_t i, uint32_t mode, uint32_t flags, uint32_t boff,
                                                 uint32_t blen, uint64_t len_tag, uint8_t* lds) {
   const int lane = lane_id();
@@ -66,7 +69,7 @@ __device__ __forceinline__ void canon_body_wave(const BatchDev& B, uint32_t i, u
       src_is_raw = 1;
     }
   } else {
-    // 4 consecutive bytes per lane, 256 B per step.  Loads run four steps (1 KB) ahead of their use, so a step
+    // 4 consecutive bytes per lane, 256 B per step.  Loads run eight steps (2 KB) ahead of their use, so a step
     // never waits for HBM; output bytes are compacted into LDS and leave in 16-byte lane-contiguous stores every
     // four steps instead of eight predicated byte stores per step.
     typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
@@ -78,24 +81,53 @@ __device__ __forceinline__ void canon_body_wave(const BatchDev& B, uint32_t i, u
       return v;
     };
     uint32_t o = 0;                           // bytes already in regB
-    uint32_t q[4];                            // the next four 256-byte windows, one dword per lane each
+    constexpr int RING = 8;                   // windows in flight: 2 KB of loads ahead of their use
+    uint32_t q[RING];                         // the next RING 256-byte windows, one dword per lane each
 #pragma unroll
-    for (int k = 0; k < 4; k++) q[k] = load4(256u * k + 4 * lane);
+    for (int k = 0; k < RING; k++) q[k] = load4(256u * k + 4 * lane);
     uint32_t prev_last = OOB;                 // byte before this step's 256-byte window
-    for (uint32_t base0 = 0; base0 < blen; base0 += 1024) {
-      uint32_t fill = 0;                      // bytes compacted into LDS by this group of steps (<= 4 * 512)
+    uint32_t fill = 0;                        // bytes compacted into LDS and not yet stored
+    uint32_t last_in = OOB;                   // last byte of the body
+    bool tail_done = false;
+    for (uint32_t base0 = 0; base0 < blen; base0 += 256u * RING) {
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
+      for (int k = 0; k < RING; k++) {
         const uint32_t base = base0 + 256u * k;
         if (base < blen) {                    // wave-uniform
           const uint32_t cur = q[k];
-          q[k] = load4(base + 1024 + 4 * lane);                                    // four steps ahead
-          const uint32_t nxtw = q[(k + 1) & 3];                                    // the window after this one
+          q[k] = load4(base + 256u * RING + 4 * lane);                             // RING steps ahead
+          const uint32_t nxtw = q[(k + 1) & (RING - 1)];                                    // the window after this one
           const uint32_t pos0 = base + 4 * lane;
           uint32_t pv = lane_down(cur >> 24); if (lane == 0) pv = prev_last;       // byte in front of my 4
           uint32_t nb = lane_up(cur & 0xff);                                        // byte after my 4
           const uint32_t nfirst = __builtin_amdgcn_readfirstlane(nxtw) & 0xff;
           if (lane == 63) nb = (base + 256 < blen) ? nfirst : OOB;
+          const uint32_t lastb = __builtin_amdgcn_readlane(cur, 63) >> 24;
+          if (base + 256 >= blen) {           // the window that holds the last byte of the body
+            const uint32_t ix = blen - 1 - base;
+            last_in = (__builtin_amdgcn_readlane(cur, ix >> 2) >> (8 * (ix & 3))) & 0xff;
+          }
+          // Clean window: a full 256 bytes with no TAB, no WSP in front of WSP or CR, and no WSP at either edge
+          // leaves relaxed canonicalisation as it came (a single SP between words stays one SP) — copy it.
+          {
+            bool need = false;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              const uint32_t c = (cur >> (8 * j)) & 0xff;
+              const uint32_t n = (j < 3) ? ((cur >> (8 * (j + 1))) & 0xff) : nb;
+              need = need || c == '\t' || (c == ' ' && (n == ' ' || n == '\t' || n == '\r'));
+            }
+            if (base + 256 <= blen && !is_wsp(prev_last) && !is_wsp(lastb) && __ballot(need) == 0) {
+              if ((fill & 3u) == 0) *(uint32_t*)(lds + fill + 4 * lane) = cur;
+              else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) lds[fill + 4 * lane + j] = (uint8_t)(cur >> (8 * j));
+              }
+              fill += 256;
+              prev_last = lastb;
+              continue;
+            }
+          }
           // up to 8 output bytes of this lane, appended into a 64-bit shift register (no indexed register array)
           uint64_t out64 = 0;
           uint32_t sh = 0;                    // 8 * bytes appended
@@ -134,28 +166,51 @@ __device__ __forceinline__ void canon_body_wave(const BatchDev& B, uint32_t i, u
             lds[at] = (uint8_t)(out64 >> (8 * t));
           }
           fill += total;
-          prev_last = __builtin_amdgcn_readlane(cur, 63) >> 24;
+          prev_last = lastb;
         }
       }
-      // flush the group: 16 bytes per lane and store, then the (< 16) byte tail
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      for (uint32_t bq = 16u * lane; bq + 16 <= fill; bq += 1024) *(uint4_store_unaligned*)(regB + o + bq) = *(const uint4*)(lds + bq);
-      {
-        const uint32_t tb = (fill & ~15u) + lane;
-        if (lane < 16 && tb < fill) regB[o + tb] = lds[tb];
+      // Flush when another group (at most 256 * RING + 1 bytes of output) might not fit, or at the end.  Few, large flushes:
+      // on gfx9 stores share vmcnt with the loads, so every flush is a point where the prefetched loads behind it
+      // have to wait for store acknowledgements.
+      const bool last_group = base0 + 256u * RING >= blen;
+      if (fill + 256u * RING + 4 > CANON_LDS_TRASH || last_group) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (last_group) {
+          // The end of the body, settled on the bytes still in LDS (no trip through memory):
+          // a WSP run that ends the body is not followed by CRLF, so its single SP stays; then trailing empty
+          // lines are cut to one CRLF, or a missing final CRLF is added.
+          if (is_wsp(last_in)) { if (lane == 0) lds[fill] = ' '; fill++; }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          bool ended = false;
+          const uint32_t m = trailing_crlf_pairs([&](uint32_t l) { return (uint32_t)lds[l]; }, fill, &ended);
+          if (ended || o == 0) {               // the run of CRLFs ends inside LDS (or LDS holds the whole output)
+            if (m >= 2) fill -= 2 * (m - 1);
+            else if (o + fill > 0 && m == 0) { if (lane < 2) lds[fill + lane] = lane ? '\n' : '\r'; fill += 2; }
+            tail_done = true;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+          }
+        }
+        for (uint32_t bq = 16u * lane; bq + 16 <= fill; bq += 1024) *(uint4_store_unaligned*)(regB + o + bq) = *(const uint4*)(lds + bq);
+        {
+          const uint32_t tb = (fill & ~15u) + lane;
+          if (lane < 16 && tb < fill) regB[o + tb] = lds[tb];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        o += fill;
+        fill = 0;
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      o += fill;
     }
-    // a WSP run that ends the body is not followed by CRLF: its single SP stays
-    if (blen && is_wsp((uint32_t)body[blen - 1])) { if (lane == 0) regB[o] = ' '; o++; }
-    // trailing empty lines / missing final CRLF, on the bytes just written
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    const uint32_t m = trailing_crlf_pairs([&](uint32_t l) { return ld_coherent_u8(regB + l); }, o);
-    if (m >= 2) o -= 2 * (m - 1);
-    else if (o > 0 && m == 0) { if (lane < 2) regB[o + lane] = lane ? '\n' : '\r'; o += 2; }
+    // trailing empty lines / missing final CRLF when the last flush could not settle them from LDS
+    if (!tail_done) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      const uint32_t m = trailing_crlf_pairs([&](uint32_t l) { return ld_coherent_u8(regB + l); }, o);
+      if (m >= 2) o -= 2 * (m - 1);
+      else if (o > 0 && m == 0) { if (lane < 2) regB[o + lane] = lane ? '\n' : '\r'; o += 2; }
+    }
     full = o;
   }
   uint32_t hashed = full;
