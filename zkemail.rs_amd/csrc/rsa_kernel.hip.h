@@ -41,13 +41,17 @@ __device__ __forceinline__ void rsa_wave(const RsaJob* __restrict__ jobs, uint32
     if (cache) {
       kh = (const uint32_t*)(key_hash_base + (size_t)job * hash_stride);
       E = cache + (kh[0] % KEY_CACHE_SLOTS);
-      if (__hip_atomic_load(&E->state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2u) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        const bool same = (lane < 8) ? (E->hash[lane] == kh[lane]) : true;
-        if (ballot64(!same) == 0 && E->bits == bits) {
+      // Every access to an entry is an agent-scope atomic (sc1: served at the coherence point, not from this XCD's
+      // L2), so no fence is needed on either side: an agent-scope acquire / release on this chip is an L2
+      // invalidate / write-back, paid by every wave of the launch and by whatever else runs on the XCD.
+      // The entry is immutable once state == 2, and the state load is waited for before the other loads issue.
+      auto ld = [](const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+      if (ld(&E->state) == 2u) {
+        const bool same = (lane < 8) ? (ld(&E->hash[lane]) == kh[lane]) : true;
+        if (ballot64(!same) == 0 && ld(&E->bits) == bits) {
 #pragma unroll
-          for (int q = 0; q < NL; q++) rr.v[q] = E->rr[q * 64 + lane];
-          ninv = E->ninv;
+          for (int q = 0; q < NL; q++) rr.v[q] = ld(&E->rr[q * 64 + lane]);
+          ninv = ld(&E->ninv);
           hit = true;
         }
       }
@@ -82,13 +86,13 @@ __device__ __forceinline__ void rsa_wave(const RsaJob* __restrict__ jobs, uint32
         if (lane == 0) won = atomicCAS(&E->state, 0u, 1u) == 0u ? 1u : 0u;
         won = __builtin_amdgcn_readfirstlane(won);
         if (won) {
-          if (lane < 8) E->hash[lane] = kh[lane];
-          if (lane == 0) { E->ninv = ninv; E->bits = bits; }
+          auto st = [](uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+          if (lane < 8) st(&E->hash[lane], kh[lane]);
+          if (lane == 0) { st(&E->ninv, ninv); st(&E->bits, bits); }
 #pragma unroll
-          for (int q = 0; q < NL; q++) E->rr[q * 64 + lane] = rr.v[q];
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          if (lane == 0) __hip_atomic_store(&E->state, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (int q = 0; q < NL; q++) st(&E->rr[q * 64 + lane], rr.v[q]);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the entry has reached the coherence point ...
+          if (lane == 0) st(&E->state, 2u);                        // ... before it is published
         }
       }
     }
