@@ -38,9 +38,10 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c4shard", "c5", "c2ed"],
+    ap.add_argument("--workload", default="c2", choices=["c2", "c4shard", "c5", "c2ed", "c3", "c5re"],
                     help="c2 = BASELINE configs[1] (default); c4shard = one GPU's shard of configs[3]; c5 = configs[4] shape; "
-                         "c2ed = the c2 shape signed a=ed25519-sha256 (SURVEY §8(f) row f4)")
+                         "c2ed = the c2 shape signed a=ed25519-sha256 (SURVEY §8(f) row f4); c3 = configs[2] (verify_email_with_regex, "
+                         "2 header parts); c5re = configs[4] shape (RSA-4096, QP soft breaks, 2 header + 2 body parts)")
     ap.add_argument("--batch", type=int, default=0, help="override e-mails per step (default: the config's batch)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU baseline sample budget per leg")
     ap.add_argument("--no-cpu", action="store_true")
@@ -53,7 +54,8 @@ def parse_args():
 
 
 def device_batch(torch, wl_batch, dev):
-    """Move a PackedBatch to HBM as uint8 / int64 tensors and build a zke_batch of device pointers."""
+    """Move a PackedBatch to HBM as uint8 / int64 tensors and build a zke_batch of device pointers.
+    Regex batches: the part-id lists stay host arrays (the C-ABI says so), the captures go to HBM."""
     from zkemail_rs_amd import _abi as A
 
     def t(arr):
@@ -72,6 +74,14 @@ def device_batch(torch, wl_batch, dev):
     b.key_blob = keep["key"].data_ptr(); b.key_off = keep["key_off"].data_ptr()
     b.key_type = keep["ktype"].data_ptr(); b.ext_null = keep["ext"].data_ptr()
     b.with_regex = 0
+    if wl_batch.c.with_regex:
+        for name in ("cap_off", "cap_str_off", "cap_blob"):
+            keep[name] = t(np.concatenate([np.asarray(getattr(wl_batch, name)).view(np.uint8), np.zeros(64, np.uint8)]))
+        keep["hdr_ids"], keep["body_ids"] = wl_batch.hdr_ids, wl_batch.body_ids            # host arrays, kept alive
+        b.with_regex = 1
+        b.n_header_parts, b.n_body_parts = wl_batch.c.n_header_parts, wl_batch.c.n_body_parts
+        b.header_part_ids, b.body_part_ids = wl_batch.hdr_ids.ctypes.data, wl_batch.body_ids.ctypes.data
+        b.cap_off, b.cap_str_off, b.cap_blob = (keep[k].data_ptr() for k in ("cap_off", "cap_str_off", "cap_blob"))
     totals = (int(wl_batch.raw_off[-1]), int(wl_batch.domain_off[-1]), int(wl_batch.key_off[-1]))
     return b, keep, totals
 
@@ -112,21 +122,32 @@ def main():
         "c4shard": dict(n=8192, body_len=65536, rsa_bits=2048, n_keys=16),
         "c5": dict(n=2048, body_len=4096, rsa_bits=4096, n_keys=16, qp_frac=0.05),
         "c2ed": dict(n=1024, body_len=4096, n_keys=16, algo="ed25519-sha256"),
+        "c3": dict(n=4096, body_len=4096, rsa_bits=2048, n_keys=16, n_header_parts=2, n_body_parts=0),
+        "c5re": dict(n=2048, body_len=4096, rsa_bits=4096, n_keys=16, n_header_parts=2, n_body_parts=2, qp_frac=0.05),
     }
     cfg = dict(cfgs[args.workload])
     if args.batch:
         cfg["n"] = args.batch
     t0 = time.time()
-    wl = synth.make_workload(args.workload, seed=1000 + rank, **cfg)
+    regex_inputs = None
+    if "n_header_parts" in cfg:
+        regex_inputs, wl, _ = synth.make_regex_workload(args.workload, seed=1000 + rank, **cfg)
+    else:
+        wl = synth.make_workload(args.workload, seed=1000 + rank, **cfg)
     gen_s = time.time() - t0
-    packed = A.PackedBatch(wl.emails)
-    cb, keep, totals = device_batch(torch, packed, dev)
-    n = packed.n
     S = max(1, args.streams)
     # S independent batches in flight: one engine (workspace) + one HIP stream + one result buffer each.
     # The inputs are read-only and shared.  A step is still one batch of n e-mails; consecutive steps
     # simply do not wait for each other, as a service with a queue of batches would run them.
     engines = [z.Engine(device=local_rank) for _ in range(S)]
+    if regex_inputs is not None:
+        packed = engines[0].pack_with_regex(regex_inputs)           # registers the DFAs of the part list
+        for e in engines[1:]:                                        # same DFAs, same order -> same ids on every engine
+            e.pack_with_regex(regex_inputs[:1])
+    else:
+        packed = A.PackedBatch(wl.emails)
+    cb, keep, totals = device_batch(torch, packed, dev)
+    n = packed.n
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     results_s = [torch.zeros(n * 192, dtype=torch.uint8, device=dev) for _ in range(S)]
     gathered_s = [torch.zeros(world * n * 192, dtype=torch.uint8, device=dev) if use_dist else None for _ in range(S)]
@@ -261,13 +282,14 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu:
         import oracle_lib
         orc = oracle_lib.load()
+        cpu_packed = orc.pack_with_regex(regex_inputs) if regex_inputs is not None else packed     # the oracle has its own DFA registry
         cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
 
         def cpu_leg(threads):
             reps, t_used = 0, 0.0
             t_start = time.perf_counter()
             while t_used < args.cpu_seconds:
-                r = orc.verify_batch(packed, threads=threads)
+                r = orc.verify_batch(cpu_packed, threads=threads)
                 reps += 1
                 t_used = time.perf_counter() - t_start
             assert (r["status"] == 0).all()
