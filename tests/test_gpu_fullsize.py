@@ -76,3 +76,24 @@ def test_config4_slice(engine):
     wl = synth.make_workload("c4", 512, 65536, rsa_bits=2048, n_keys=16, seed=4)
     assert wl.body_bytes == 512 * 65536
     check_workload(engine, wl, A.PackedBatch(wl.emails))
+
+
+def test_config2_shape_ed25519(engine):
+    """The configs[1] shape signed a=ed25519-sha256 (row f4): 1 024 Ed25519 verifications in one batch (16 waves of
+    the lane-per-signature kernel), every record checked against the signer's hashes; then one flipped signature bit."""
+    wl = synth.make_workload("c2ed", 1024, 4096, n_keys=16, seed=6, algo="ed25519-sha256")
+    packed = A.PackedBatch(wl.emails)
+    got = check_workload(engine, wl, packed)
+    assert ((got["flags"] & A.F_ED25519) != 0).all() and (got["rsa_bits"] == 0).all()
+    import base64
+    e = wl.emails[77]
+    raw = e.raw_email
+    i = raw.find(b" b=") + 3
+    j = raw.find(b"\r\nReceived", i)
+    sig = bytearray(base64.b64decode(raw[i:j].replace(b"\r\n ", b"")))
+    sig[40] ^= 0x10
+    emails = list(wl.emails)
+    emails[77] = A.Email(e.from_domain, raw[:i] + base64.b64encode(bytes(sig)) + raw[j:], e.public_key)
+    got2 = engine.verify_batch(A.PackedBatch(emails))
+    changed = [k for k in range(1024) if got2[k].tobytes() != got[k].tobytes()]
+    assert changed == [77] and int(got2[77]["status"]) == A.ZKE_DKIM_NOT_PASS and int(got2[77]["detail"]) == A.D_SIG_MISMATCH
