@@ -181,7 +181,7 @@ typedef struct zke_options {
    *              e-mail's earlier same-domain signature failed and a later one exists).
    * reserved[1]: signature rounds in device mode (default 1; fixed, nothing is read back).  An e-mail that
    *              needs more reports ZKE_UNSUPPORTED / ZKE_D_U_TOO_MANY_SIGS.
-     * reserved[2]: non-zero enables an EXPERIMENTAL hipGraph replay of the device-mode launch sequence (off by default).
+   * reserved[2]: unused (0).
    * reserved[3]: non-zero disables the per-key Montgomery-constant cache of the RSA kernel.  Others: 0. */
   uint32_t reserved[7];
 } zke_options;

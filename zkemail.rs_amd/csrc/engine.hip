@@ -54,18 +54,6 @@ struct RegisteredDfa {
 inline uint32_t e_k(uint32_t bits) { return (bits + 7) / 8; }
 constexpr int SHA_TILE = 128;
 
-struct GraphKey {          // everything the captured launch sequence depends on
-  zke_batch batch; uint64_t raw_total; zke_result* out; uint32_t rounds; uint32_t n_ids; uint64_t ids_hash;
-  bool operator==(const GraphKey& o) const {
-    const zke_batch &a = batch, &b = o.batch;
-    return a.n == b.n && a.raw_blob == b.raw_blob && a.raw_off == b.raw_off && a.domain_blob == b.domain_blob &&
-           a.domain_off == b.domain_off && a.key_blob == b.key_blob && a.key_off == b.key_off && a.key_type == b.key_type &&
-           a.ext_null == b.ext_null && a.with_regex == b.with_regex && a.n_header_parts == b.n_header_parts &&
-           a.n_body_parts == b.n_body_parts && a.cap_off == b.cap_off && a.cap_str_off == b.cap_str_off &&
-           a.cap_blob == b.cap_blob && raw_total == o.raw_total && out == o.out && rounds == o.rounds && n_ids == o.n_ids &&
-           ids_hash == o.ids_hash;
-  }
-};
 
 }  // namespace
 
@@ -90,11 +78,6 @@ struct zke_engine {
   DevBuf lanews;  // LaneWs[n]: per-e-mail header table / tag records / tag values of the front kernel
   DevBuf pending; // device counter: e-mails that need another signature round
   std::vector<RegisteredDfa*> dfas;
-  // hipGraph replay of the device-mode pipeline (see zke_verify_batch_device)
-  bool use_graphs = false;          // experimental, off: see zke_verify_batch_device
-  hipGraphExec_t graph_exec = nullptr;
-  bool graph_key_valid = false;
-  GraphKey graph_key{};
   int sha_tile = SHA_TILE;
   bool front_attr_set = false;
   bool wave_parse = true;           // front end: one e-mail per wavefront (parse.hip.h); ZKE_LANE_PARSE=1 selects the
@@ -192,14 +175,12 @@ int zke_engine_create(const zke_options* opt, zke_engine** out) {
   }
   if (opt && opt->reserved[0]) e->max_sig_rounds = std::min<uint32_t>(opt->reserved[0], 8);
   if (opt && opt->reserved[1]) e->device_mode_rounds = std::min<uint32_t>(opt->reserved[1], 8);
-  if (getenv("ZKE_GRAPHS")) e->use_graphs = true;
   if (getenv("ZKE_LANE_PARSE")) e->wave_parse = false;
   if (const char* st = getenv("ZKE_SHA_TILE")) e->sha_tile = atoi(st);
   if (getenv("ZKE_DEBUG_SKIP_RSA")) e->debug_skip_rsa = 1;
   if (getenv("ZKE_DEBUG_SKIP_ED")) e->debug_skip_ed = 1;
   if (getenv("ZKE_NO_FUSE_CANON")) e->fuse_canon = 0;
   if (const char* ds = getenv("ZKE_DEBUG_PARSE_STOP")) e->debug_parse_stop = (uint32_t)atoi(ds);
-  if (opt && opt->reserved[2]) e->use_graphs = true;           // reserved[2] != 0: experimental hipGraph replay
   *out = e;
   return 0;
 }
@@ -213,7 +194,6 @@ void zke_engine_destroy(zke_engine* e) {
                     &e->rsa_jobs, &e->sha_jobs, &e->rsa_ok, &e->em_dbg, &e->scratch_off, &e->scratch, &e->clean,
                     &e->meta2, &e->misc, &e->scratch2, &e->parts, &e->pending, &e->key_cache, &e->lanews};
   for (auto* b : bufs) b->release();
-  if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
   for (auto* d : e->dfas) { d->blob.release(); d->dev.release(); delete d; }
   for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : e->ev_h2d) if (ev) (void)hipEventDestroy(ev);

@@ -298,51 +298,9 @@ int zke_verify_batch_device(zke_engine* e, const zke_batch* in, uint64_t raw_tot
   // device mode runs a fixed number of signature rounds (options.reserved[1], default 1) without reading anything back
   const uint32_t rounds = e->device_mode_rounds;
   hipStream_t s = stream ? (hipStream_t)stream : e->stream;
-  if (e->timing || !e->use_graphs)
-    return run_device_pipeline(e, in, raw_total, out_dev, s, false, 0, rounds, rounds, true);
-
-  // EXPERIMENTAL, OFF BY DEFAULT (options.reserved[2] / ZKE_GRAPHS=1).  Idea: a service re-submits batches that
-  // live in the same staging buffers, so the kernel sequence could be captured into a hipGraph the second time an
-  // identical descriptor is seen and replayed afterwards.  Measured on MI355X with 16 batches in flight the eager
-  // path is not host-bound (same e-mails/s), and replaying the captured graph faulted in testing (round 1,
-  // tools/devmode_diag.py), so the engine launches eagerly.
-  GraphKey key{};
-  key.batch = *in; key.raw_total = raw_total; key.out = out_dev; key.rounds = rounds;
-  key.n_ids = (uint32_t)(e->host_hdr_ids.size() + e->host_body_ids.size());
-  uint64_t idh = 1469598103934665603ull;
-  for (uint32_t v : e->host_hdr_ids) idh = (idh ^ v) * 1099511628211ull;
-  for (uint32_t v : e->host_body_ids) idh = (idh ^ (v + 0x9e3779b9u)) * 1099511628211ull;
-  key.ids_hash = idh;
-  key.batch.header_part_ids = nullptr; key.batch.body_part_ids = nullptr;      // host arrays: compared through ids_hash
-  if (e->graph_exec && key == e->graph_key) {
-    HIPCHK(e, hipGraphLaunch(e->graph_exec, s));
-    return 0;
-  }
-  const bool seen_once = e->graph_key_valid && key == e->graph_key;
-  if (!seen_once) {                       // first sighting: run eagerly (sizes workspaces, sets kernel attributes)
-    if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
-    e->graph_key = key; e->graph_key_valid = true;
-    return run_device_pipeline(e, in, raw_total, out_dev, s, false, 0, rounds, rounds, true);
-  }
-  hipGraph_t g = nullptr;
-  HIPCHK(e, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-  const int r = run_device_pipeline(e, in, raw_total, out_dev, s, false, 0, rounds, rounds, true);
-  const hipError_t ce = hipStreamEndCapture(s, &g);
-  if (r || ce != hipSuccess || !g) {
-    if (g) (void)hipGraphDestroy(g);
-    e->use_graphs = false;                // capture is an optimisation only: fall back to eager launches
-    return r ? r : run_device_pipeline(e, in, raw_total, out_dev, s, false, 0, rounds, rounds, true);
-  }
-  hipGraphExec_t ge = nullptr;
-  const hipError_t ie = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
-  (void)hipGraphDestroy(g);
-  if (ie != hipSuccess || !ge) {
-    e->use_graphs = false;
-    return run_device_pipeline(e, in, raw_total, out_dev, s, false, 0, rounds, rounds, true);
-  }
-  e->graph_exec = ge;
-  HIPCHK(e, hipGraphLaunch(e->graph_exec, s));
-  return 0;
+  // Launched eagerly: four kernels per batch.  (A hipGraph capture / replay of this sequence was tried in round 1:
+  // the eager path is not host-bound, and the replay faulted — it was removed rather than kept as a switch.)
+  return run_device_pipeline(e, in, raw_total, out_dev, s, false, 0, rounds, rounds, true);
 }
 
 int zke_verify_batch(zke_engine* e, const zke_batch* in, zke_result* out, zke_debug_out* dbg) {
