@@ -225,12 +225,12 @@ def main():
     if args.workload == "c2" and not args.batch and os.path.exists(pmc_file):
         traffic = int(json.load(open(pmc_file))["hbm_bytes_per_launch"])
     roof = {
-        "bound": "hbm", "kernel": "sha256_batch_kernel<128>", "achieved": round(sha_bytes / sha_s / 1e9, 3) if sha_s > 0 else None,
+        "bound": "hbm", "kernel": "sha256_pair_kernel<128>" if (4 * ((n + 63) // 64)) <= 512 else "sha256_batch_kernel<128>", "achieved": round(sha_bytes / sha_s / 1e9, 3) if sha_s > 0 else None,
         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(sha_bytes / sha_s / 1e9 / HBM_PEAK_GBS, 5) if sha_s > 0 else None,
         "traffic": traffic, "bytes_per_launch": sha_bytes, "launch_us": round(kern["sha_us"], 2),
         "note": "SHA-256 on CDNA4 is integer-VALU bound: the compression alone sustains 1.82 TB/s on this chip "
                 "(profiles/r01_ubench_sha_alu.txt; v_alignbit/v_add3 issue at half rate), and a 1024-message launch is "
-                "bounded by the 65-block dependency chain of one message; see DESIGN.md §3",
+                "bounded by the 65-block dependency chain of one message (split over two waves: schedule / rounds); see DESIGN.md §3",
     }
 
     # ---- the same SHA-256 kernel with enough independent messages to fill the chip (kernel capability, not the

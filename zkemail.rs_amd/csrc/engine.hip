@@ -53,6 +53,7 @@ struct RegisteredDfa {
 
 inline uint32_t e_k(uint32_t bits) { return (bits + 7) / 8; }
 constexpr int SHA_TILE = 128;
+constexpr uint32_t SHA_PAIR_MAX_GROUPS = 512;      // launches of up to 32 768 messages use two waves per 64 messages
 
 
 }  // namespace
@@ -79,6 +80,7 @@ struct zke_engine {
   DevBuf pending; // device counter: e-mails that need another signature round
   std::vector<RegisteredDfa*> dfas;
   int sha_tile = SHA_TILE;
+  int sha_pair = -1;                // two-wave SHA-256 kernel: -1 by launch size, 0 never, 1 always (ZKE_SHA_PAIR)
   bool front_attr_set = false;
   bool wave_parse = true;           // front end: one e-mail per wavefront (parse.hip.h); ZKE_LANE_PARSE=1 selects the
                                     // one-e-mail-per-lane variant (front.hip.h), see DESIGN.md §3
@@ -110,6 +112,21 @@ int launch_sha(zke_engine* e, const ShaJob* jobs, uint32_t n, hipStream_t s) {
     HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&sha256_batch_kernel<T>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
+  }
+  // Few messages: the launch is as long as one wave's chain of compressions, so split the chain over two waves
+  // (sha256_pair_kernel).  Many messages: the chip is full and the one-wave kernel does less LDS work per byte.
+  const uint32_t groups = (n + 63) / 64;
+  if (e->sha_pair == 1 || (e->sha_pair < 0 && groups <= SHA_PAIR_MAX_GROUPS)) {
+    static bool pair_attr_set = false;
+    const size_t plds = sha256_pair_lds_bytes<T>();
+    if (!pair_attr_set) {
+      HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&sha256_pair_kernel<T>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
+      pair_attr_set = true;
+    }
+    hipLaunchKernelGGL(sha256_pair_kernel<T>, dim3(groups), dim3(128), plds, s, jobs, n);
+    HIPCHK(e, hipGetLastError());
+    return 0;
   }
   const uint32_t grid = (n + 255) / 256;
   hipLaunchKernelGGL(sha256_batch_kernel<T>, dim3(grid), dim3(256), lds, s, jobs, n);
@@ -177,6 +194,7 @@ int zke_engine_create(const zke_options* opt, zke_engine** out) {
   if (opt && opt->reserved[1]) e->device_mode_rounds = std::min<uint32_t>(opt->reserved[1], 8);
   if (getenv("ZKE_LANE_PARSE")) e->wave_parse = false;
   if (const char* st = getenv("ZKE_SHA_TILE")) e->sha_tile = atoi(st);
+  if (const char* sp = getenv("ZKE_SHA_PAIR")) e->sha_pair = atoi(sp);
   if (getenv("ZKE_DEBUG_SKIP_RSA")) e->debug_skip_rsa = 1;
   if (getenv("ZKE_DEBUG_SKIP_ED")) e->debug_skip_ed = 1;
   if (getenv("ZKE_NO_FUSE_CANON")) e->fuse_canon = 0;

@@ -225,4 +225,213 @@ __global__ __launch_bounds__(256) void sha256_batch_kernel(const ShaJob* __restr
 template <int T>
 constexpr size_t sha256_lds_bytes() { return 4 * (64 * (T + 16) + 64 * 16); }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Two waves per 64 messages, for launches with few messages (the BASELINE batch: 1 024 bodies = 16 groups on a
+// chip with 1 024 SIMDs).  Such a launch lasts as long as ONE wave needs for the longest message's chain of
+// compressions, and a lone wave issues one instruction every ~4.3 cycles however independent its instructions
+// are — so the only way to shorten the chain is to put fewer instructions on it.  The message schedule
+// (W[16..63], ~480 VALU per block) does not depend on the chaining state: wave 0 (feeder) fetches the bytes,
+// builds K[t] + W[t] for block k+1 and leaves the 64 words per lane in LDS while wave 1 (rounds) runs the 64
+// rounds of block k on what the feeder left the step before.  One s_barrier per block; ~900 instead of ~1 400
+// instructions on the critical path.  Groups that contain a SHA-1 job fall back to the one-wave routine.
+// LDS per group: slab 64 x (T+16) + descriptors 1 KB + 2 x 64 x 64 x 4 B of K+W.
+constexpr uint32_t SHA_K[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
+    0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+    0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+    0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+    0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+    0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
+    0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+
+template <int T>
+constexpr size_t sha256_pair_lds_bytes() { return 64 * (T + 16) + 64 * 16 + 2 * 64 * 64 * 4; }
+
+template <int T>
+__global__ __launch_bounds__(128) void sha256_pair_kernel(const ShaJob* __restrict__ jobs, uint32_t n) {
+  static_assert(T % 64 == 0 && T >= 64 && T <= 1024, "tile must be whole SHA blocks");
+  constexpr int ROW = T + 16;
+  constexpr int LPR = T / 16;
+  constexpr int RPI = 64 / LPR;
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+  __builtin_amdgcn_s_setprio(3);
+  const int lane = threadIdx.x & 63;
+  const int role = threadIdx.x >> 6;               // 0 feeder, 1 rounds
+  uint8_t* slab = lds_raw;
+  uint8_t* desc = slab + 64 * ROW;
+  uint32_t* kw = (uint32_t*)(desc + 64 * 16);      // [2][64 words][64 lanes]
+
+  const uint32_t m = blockIdx.x * 64 + lane;       // both waves look at the same 64 jobs
+  uint64_t my_src = 0, my_dst = 0;
+  uint32_t my_len = 0, my_nblk = 0, my_algo = 0;
+  if (m < n) {
+    ShaJob j = jobs[m];
+    my_src = j.src; my_dst = j.dst; my_len = j.len; my_algo = j.pad;
+    my_nblk = my_dst ? (my_len + 9 + 63) >> 6 : 0;
+  }
+  uint32_t max_nblk = my_nblk;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) max_nblk = max(max_nblk, (uint32_t)__shfl_xor((int)max_nblk, o));
+  max_nblk = __builtin_amdgcn_readfirstlane(max_nblk);
+  const bool any_sha1 = __ballot(my_algo != 0) != 0;          // the same in both waves: they read the same jobs
+
+  uint32_t st[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+  uint8_t* my_row = slab + lane * ROW;
+
+  if (role == 0) {
+    *(uint64_t*)(desc + lane * 16) = my_src;
+    *(uint32_t*)(desc + lane * 16 + 8) = my_len;
+    *(uint32_t*)(desc + lane * 16 + 12) = my_nblk;
+  }
+  uint4 stage[LPR];
+  uint32_t live = 0;
+  auto fetch = [&](uint32_t blk0) {
+    const uint32_t tile_off = blk0 * 64;
+    live = 0;
+#pragma unroll
+    for (int g = 0; g < LPR; g++) {
+      const int row = g * RPI + lane / LPR;
+      const int chunk = lane % LPR;
+      const uint64_t rsrc = *(const uint64_t*)(desc + row * 16);
+      const uint32_t rlen = *(const uint32_t*)(desc + row * 16 + 8);
+      const uint32_t rnblk = *(const uint32_t*)(desc + row * 16 + 12);
+      const uint32_t off = tile_off + chunk * 16;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (blk0 < rnblk) {
+        live |= 1u << g;
+        if (off + 16 <= rlen) {
+          v = *(const uint4_unaligned*)(rsrc + off);
+        } else if (off < rlen) {
+          const uint8_t* p = (const uint8_t*)(rsrc + off);
+          uint32_t rem = rlen - off, t[4] = {0, 0, 0, 0};
+          for (uint32_t b = 0; b < rem; b++) t[b >> 2] |= (uint32_t)p[b] << (8 * (b & 3));
+          v = make_uint4(t[0], t[1], t[2], t[3]);
+        }
+      }
+      stage[g] = v;
+    }
+  };
+  auto commit = [&](uint32_t blk0) {
+    const uint32_t tile_off = blk0 * 64;
+#pragma unroll
+    for (int g = 0; g < LPR; g++) {
+      const int row = g * RPI + lane / LPR;
+      const int chunk = lane % LPR;
+      if (live & (1u << g)) *(uint4*)(slab + row * ROW + chunk * 16) = stage[g];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (blk0 < my_nblk) {
+      if (my_len >= tile_off && my_len < tile_off + T) my_row[my_len - tile_off] = 0x80;
+      const uint32_t last = my_nblk - 1;
+      if (last >= blk0 && last < blk0 + T / 64) {
+        const uint64_t bits = (uint64_t)my_len * 8;
+        uint32_t* tail = (uint32_t*)(my_row + (last - blk0) * 64 + 56);
+        tail[0] = __builtin_bswap32((uint32_t)(bits >> 32));
+        tail[1] = __builtin_bswap32((uint32_t)bits);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  if (any_sha1) {
+    // one-wave routine (as sha256_batch_kernel) by the feeder; the other wave has nothing to do.  No barrier below.
+    if (role != 0) return;
+    if (my_algo) { st[0] = 0x67452301; st[1] = 0xEFCDAB89; st[2] = 0x98BADCFE; st[3] = 0x10325476; st[4] = 0xC3D2E1F0; st[5] = st[6] = st[7] = 0; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (max_nblk) { fetch(0); commit(0); }
+    for (uint32_t blk0 = 0; blk0 < max_nblk; blk0 += T / 64) {
+      const uint32_t next = blk0 + T / 64;
+      const bool more = next < max_nblk;
+      if (more) fetch(next);
+#pragma unroll 1
+      for (int b = 0; b < T / 64; b++) {
+        if (blk0 + b < my_nblk) {
+          uint32_t w[16];
+          const uint4* src = (const uint4*)(my_row + b * 64);
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            uint4 v = src[q];
+            w[4 * q + 0] = __builtin_bswap32(v.x); w[4 * q + 1] = __builtin_bswap32(v.y);
+            w[4 * q + 2] = __builtin_bswap32(v.z); w[4 * q + 3] = __builtin_bswap32(v.w);
+          }
+          if (my_algo) sha1_compress(st, w); else sha256_compress(st, w);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (more) commit(next);
+    }
+  } else {
+    // feeder: K+W of block kb into kw[kb & 1]
+    auto sched = [&](uint32_t kb) {
+      uint32_t w[16];
+      const uint4* src = (const uint4*)(my_row + (kb % (T / 64)) * 64);
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        uint4 v = src[q];
+        w[4 * q + 0] = __builtin_bswap32(v.x); w[4 * q + 1] = __builtin_bswap32(v.y);
+        w[4 * q + 2] = __builtin_bswap32(v.z); w[4 * q + 3] = __builtin_bswap32(v.w);
+      }
+      uint32_t* dst = kw + (kb & 1) * (64 * 64) + lane;
+#pragma unroll
+      for (int i = 0; i < 64; i++) {
+        uint32_t wi;
+        if (i < 16) {
+          wi = w[i];
+        } else {
+          const uint32_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
+          const uint32_t s0 = xor3(rotr32(w15, 7), rotr32(w15, 18), w15 >> 3);
+          const uint32_t s1 = xor3(rotr32(w2, 17), rotr32(w2, 19), w2 >> 10);
+          wi = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
+          w[i & 15] = wi;
+        }
+        dst[i * 64] = wi + SHA_K[i];
+      }
+    };
+    if (role == 0 && max_nblk) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      fetch(0); commit(0);
+      if (T / 64 < max_nblk) fetch(T / 64);
+      sched(0);
+    }
+    __syncthreads();
+    // Both waves run exactly max_nblk steps (same jobs, same maximum), one barrier per step.
+    for (uint32_t kb = 0; kb < max_nblk; kb++) {
+      if (role == 0) {
+        const uint32_t nb = kb + 1;
+        if (nb < max_nblk) {
+          if (nb % (T / 64) == 0) {                  // first block of the next tile: its bytes were fetched a tile ago
+            commit(nb);
+            if (nb + T / 64 < max_nblk) fetch(nb + T / 64);
+          }
+          sched(nb);
+        }
+      } else {
+        const uint32_t* src = kw + (kb & 1) * (64 * 64) + lane;
+        uint32_t a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+#pragma unroll
+        for (int i = 0; i < 64; i++) {
+          const uint32_t S1 = xor3(rotr32(e, 6), rotr32(e, 11), rotr32(e, 25));
+          const uint32_t t1 = (h + S1 + ch3(e, f, g)) + src[i * 64];
+          const uint32_t S0 = xor3(rotr32(a, 2), rotr32(a, 13), rotr32(a, 22));
+          const uint32_t mj = maj3(a, b, c);
+          h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + S0 + mj;
+        }
+        if (kb < my_nblk) { st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h; }
+      }
+      __syncthreads();
+    }
+    if (role == 0) return;
+  }
+  if (m < n && my_dst) {
+    uint32_t* out = (uint32_t*)my_dst;
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[i] = (my_algo && i >= 5) ? 0u : __builtin_bswap32(st[i]);
+  }
+}
+
 }  // namespace zke
