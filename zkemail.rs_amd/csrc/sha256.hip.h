@@ -234,7 +234,8 @@ constexpr size_t sha256_lds_bytes() { return 4 * (64 * (T + 16) + 64 * 16); }
 // builds K[t] + W[t] for block k+1 and leaves the 64 words per lane in LDS while wave 1 (rounds) runs the 64
 // rounds of block k on what the feeder left the step before.  One s_barrier per block; ~900 instead of ~1 400
 // instructions on the critical path.  Groups that contain a SHA-1 job fall back to the one-wave routine.
-// LDS per group: slab 64 x (T+16) + descriptors 1 KB + 2 x 64 x 64 x 4 B of K+W.
+// LDS per group: slab 64 x (T+16) + descriptors 1 KB + 2 x 64 lanes x 68 words of K+W (row stride 68 words = 4 banks
+// mod 64: conflict-free 16-byte writes and reads, a quarter of the LDS instructions of word accesses).
 constexpr uint32_t SHA_K[64] = {
     0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
     0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
@@ -245,8 +246,10 @@ constexpr uint32_t SHA_K[64] = {
     0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
     0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
 
+constexpr int SHA_KW_ROW = 68;        // dwords per lane and buffer
+
 template <int T>
-constexpr size_t sha256_pair_lds_bytes() { return 64 * (T + 16) + 64 * 16 + 2 * 64 * 64 * 4; }
+constexpr size_t sha256_pair_lds_bytes() { return 64 * (T + 16) + 64 * 16 + 2 * 64 * SHA_KW_ROW * 4; }
 
 template <int T>
 __global__ __launch_bounds__(128) void sha256_pair_kernel(const ShaJob* __restrict__ jobs, uint32_t n) {
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(128) void sha256_pair_kernel(const ShaJob* __restri
   const int role = threadIdx.x >> 6;               // 0 feeder, 1 rounds
   uint8_t* slab = lds_raw;
   uint8_t* desc = slab + 64 * ROW;
-  uint32_t* kw = (uint32_t*)(desc + 64 * 16);      // [2][64 words][64 lanes]
+  uint32_t* kw = (uint32_t*)(desc + 64 * 16);      // [2][64 lanes][SHA_KW_ROW]: a lane's 64 words are contiguous (b128 accesses)
 
   const uint32_t m = blockIdx.x * 64 + lane;       // both waves look at the same 64 jobs
   uint64_t my_src = 0, my_dst = 0;
@@ -375,7 +378,8 @@ __global__ __launch_bounds__(128) void sha256_pair_kernel(const ShaJob* __restri
         w[4 * q + 0] = __builtin_bswap32(v.x); w[4 * q + 1] = __builtin_bswap32(v.y);
         w[4 * q + 2] = __builtin_bswap32(v.z); w[4 * q + 3] = __builtin_bswap32(v.w);
       }
-      uint32_t* dst = kw + (kb & 1) * (64 * 64) + lane;
+      uint4* dst = (uint4*)(kw + (kb & 1) * (64 * SHA_KW_ROW) + lane * SHA_KW_ROW);
+      uint32_t o4[4];
 #pragma unroll
       for (int i = 0; i < 64; i++) {
         uint32_t wi;
@@ -388,7 +392,8 @@ __global__ __launch_bounds__(128) void sha256_pair_kernel(const ShaJob* __restri
           wi = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
           w[i & 15] = wi;
         }
-        dst[i * 64] = wi + SHA_K[i];
+        o4[i & 3] = wi + SHA_K[i];
+        if ((i & 3) == 3) dst[i >> 2] = make_uint4(o4[0], o4[1], o4[2], o4[3]);
       }
     };
     if (role == 0 && max_nblk) {
@@ -411,12 +416,15 @@ __global__ __launch_bounds__(128) void sha256_pair_kernel(const ShaJob* __restri
           sched(nb);
         }
       } else {
-        const uint32_t* src = kw + (kb & 1) * (64 * 64) + lane;
+        const uint4* src = (const uint4*)(kw + (kb & 1) * (64 * SHA_KW_ROW) + lane * SHA_KW_ROW);
+        uint4 k4 = make_uint4(0, 0, 0, 0);
         uint32_t a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
 #pragma unroll
         for (int i = 0; i < 64; i++) {
           const uint32_t S1 = xor3(rotr32(e, 6), rotr32(e, 11), rotr32(e, 25));
-          const uint32_t t1 = (h + S1 + ch3(e, f, g)) + src[i * 64];
+          if ((i & 3) == 0) k4 = src[i >> 2];
+          const uint32_t kwi = (i & 3) == 0 ? k4.x : (i & 3) == 1 ? k4.y : (i & 3) == 2 ? k4.z : k4.w;
+          const uint32_t t1 = (h + S1 + ch3(e, f, g)) + kwi;
           const uint32_t S0 = xor3(rotr32(a, 2), rotr32(a, 13), rotr32(a, 22));
           const uint32_t mj = maj3(a, b, c);
           h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + S0 + mj;
