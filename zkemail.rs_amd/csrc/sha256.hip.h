@@ -110,7 +110,10 @@ __global__ __launch_bounds__(256) void sha256_batch_kernel(const ShaJob* __restr
   // the chip: with several batches in flight its few waves share SIMDs with thousands of front-end / RSA waves and
   // the chain stretches ~2x.  Raising the wave priority keeps the chain near its unloaded latency; the other
   // kernels have parallel slack to absorb it.
-  __builtin_amdgcn_s_setprio(3);
+#ifndef ZKE_SHA_PRIO
+#define ZKE_SHA_PRIO 3
+#endif
+  __builtin_amdgcn_s_setprio(ZKE_SHA_PRIO);
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   uint8_t* slab = lds_raw + (size_t)wave * (64 * ROW + 64 * 16);
@@ -258,7 +261,10 @@ __global__ __launch_bounds__(128) void sha256_pair_kernel(const ShaJob* __restri
   constexpr int LPR = T / 16;
   constexpr int RPI = 64 / LPR;
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-  __builtin_amdgcn_s_setprio(3);
+#ifndef ZKE_SHA_PRIO
+#define ZKE_SHA_PRIO 3
+#endif
+  __builtin_amdgcn_s_setprio(ZKE_SHA_PRIO);
   const int lane = threadIdx.x & 63;
   const int role = threadIdx.x >> 6;               // 0 feeder, 1 rounds
   uint8_t* slab = lds_raw;
