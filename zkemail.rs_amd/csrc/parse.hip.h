@@ -598,7 +598,7 @@ __device__ __forceinline__ void canon_body_wave(const BatchDev& B, uint32_t i, u
 
 __device__ const uint8_t DKIM_NAME[14] = {'D', 'K', 'I', 'M', '-', 'S', 'i', 'g', 'n', 'a', 't', 'u', 'r', 'e'};
 
-__global__ __launch_bounds__(64, 4) void parse_kernel(ParseArgs A) {
+__global__ __launch_bounds__(64, 3) void parse_kernel(ParseArgs A) {
   __shared__ ParseLds L;
   const BatchDev& B = A.b;
   const uint32_t i = blockIdx.x;

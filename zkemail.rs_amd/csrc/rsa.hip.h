@@ -133,71 +133,71 @@ __device__ __forceinline__ uint32_t big_normalize(Big<NL>& r, const uint32_t (&l
 //   tl' = hi(Q) + lo(Q of lane+1)   one v_add_co_u32 with the DPP wave shift folded in, carry c2
 //   th' = c2 + c0 + c1              three v_addc_co_u32
 // 9 VALU instructions per step against 16 (seven of them register-pair moves) from the C++ below.
-// Fixed temporaries v[76:83], s[60:67] (clobbers).  Wait states (gfx940 rules): one between a VALU write and a
+// Fixed temporaries v[64:71], s[60:67] (clobbers).  Wait states (gfx940 rules): one between a VALU write and a
 // v_readfirstlane of the register, two before a DPP read.
 __device__ __forceinline__ void mont_core_64(uint32_t& tl, uint32_t& th, uint32_t a, uint32_t b, uint32_t n, uint32_t ninv) {
   asm volatile(
-      "v_mov_b32 v76, 0\n\t"
-      "v_mov_b32 v77, 0\n\t"
-      "v_mov_b32 v82, 0\n\t"
+      "v_mov_b32 v64, 0\n\t"
+      "v_mov_b32 v65, 0\n\t"
+      "v_mov_b32 v70, 0\n\t"
       "s_mov_b32 s60, 0\n\t"
       "v_readlane_b32 s61, %3, s60\n"              // b_0
       "1:\n\t"
       ".rept 4\n\t"
-      "v_mad_u64_u32 v[78:79], s[64:65], %2, s61, v[76:77]\n\t"
-      "v_mul_lo_u32 v83, v78, %5\n\t"
+      "v_mad_u64_u32 v[66:67], s[64:65], %2, s61, v[64:65]\n\t"
+      "v_mul_lo_u32 v71, v66, %5\n\t"
       "s_add_u32 s60, s60, 1\n\t"
-      "v_readfirstlane_b32 s62, v83\n\t"
-      "v_mad_u64_u32 v[80:81], s[66:67], %4, s62, v[78:79]\n\t"
+      "v_readfirstlane_b32 s62, v71\n\t"
+      "v_mad_u64_u32 v[68:69], s[66:67], %4, s62, v[66:67]\n\t"
       "v_readlane_b32 s61, %3, s60\n\t"           // next b limb (lane select 64 after the last step reads lane 0: unused)
-      "v_addc_co_u32_e64 v77, s[62:63], v82, 0, s[64:65]\n\t"       // th' = c0
-      "v_add_co_u32_dpp v76, vcc, v80, v81 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-      "v_addc_co_u32_e32 v77, vcc, 0, v77, vcc\n\t"                  // + c2
-      "v_addc_co_u32_e64 v77, s[62:63], v77, 0, s[66:67]\n\t"       // + c1
+      "v_addc_co_u32_e64 v65, s[62:63], v70, 0, s[64:65]\n\t"       // th' = c0
+      "v_add_co_u32_dpp v64, vcc, v68, v69 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "v_addc_co_u32_e32 v65, vcc, 0, v65, vcc\n\t"                  // + c2
+      "v_addc_co_u32_e64 v65, s[62:63], v65, 0, s[66:67]\n\t"       // + c1
       ".endr\n\t"
       "s_cmp_lt_u32 s60, 64\n\t"
       "s_cbranch_scc1 1b\n\t"
-      "v_mov_b32 %0, v76\n\t"
-      "v_mov_b32 %1, v77"
+      "v_mov_b32 %0, v64\n\t"
+      "v_mov_b32 %1, v65"
       : "=&v"(tl), "=&v"(th)
       : "v"(a), "v"(b), "v"(n), "s"(__builtin_amdgcn_readfirstlane(ninv))
-      : "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "vcc", "scc");
+      : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "vcc", "scc");
 }
 
 // The two-limbs-per-lane counterpart (3072 / 4096-bit moduli: limb q*64 + lane, 128 steps).  Same step, two
 // columns per lane; limb 64 (lane 0 of the upper group) hands its low word to limb 63 (lane 63 of the lower
 // group) through v_readfirstlane + v_writelane.  19 VALU per step against ~35 from the C++ below.
-// Operands: %4 %5 = a, %6 %7 = b, %8 %9 = n (lower, upper group), %10 = ninv.  Temporaries v[76:90], s[60:72].
+// Operands: %4 %5 = a, %6 %7 = b, %8 %9 = n (lower, upper group), %10 = ninv.  Temporaries v[64:78], s[60:72].
 #define ZKE_MONT128_STEP(BSRC)                                                                          \
-      "v_mad_u64_u32 v[78:79], s[64:65], %4, s61, v[76:77]\n\t"                                         \
-      "v_mad_u64_u32 v[86:87], s[68:69], %5, s61, v[84:85]\n\t"                                         \
-      "v_mul_lo_u32 v83, v78, %10\n\t"                                                                  \
+      "v_mad_u64_u32 v[66:67], s[64:65], %4, s61, v[64:65]\n\t"                                         \
+      "v_mad_u64_u32 v[74:75], s[68:69], %5, s61, v[72:73]\n\t"                                         \
+      "v_mul_lo_u32 v71, v66, %10\n\t"                                                                  \
       "s_add_u32 s60, s60, 1\n\t"                                                                       \
-      "v_readfirstlane_b32 s62, v83\n\t"                                                                \
-      "v_mad_u64_u32 v[80:81], s[66:67], %8, s62, v[78:79]\n\t"                                         \
-      "v_mad_u64_u32 v[88:89], s[70:71], %9, s62, v[86:87]\n\t"                                         \
+      "v_readfirstlane_b32 s62, v71\n\t"                                                                \
+      "v_mad_u64_u32 v[68:69], s[66:67], %8, s62, v[66:67]\n\t"                                         \
+      "v_mad_u64_u32 v[76:77], s[70:71], %9, s62, v[74:75]\n\t"                                         \
       "s_and_b32 s63, s60, 63\n\t"                                                                      \
       "v_readlane_b32 s61, " BSRC ", s63\n\t"                                                           \
-      "v_addc_co_u32_e64 v77, s[62:63], v82, 0, s[64:65]\n\t"                                           \
-      "v_addc_co_u32_e64 v85, s[62:63], v82, 0, s[68:69]\n\t"                                           \
-      "v_mov_b32_dpp v90, v80 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"                   \
-      "v_readfirstlane_b32 s72, v88\n\t"                                                                \
-      "v_writelane_b32 v90, s72, 63\n\t"                                                                \
-      "v_add_co_u32_e32 v76, vcc, v90, v81\n\t"                                                         \
-      "v_addc_co_u32_e32 v77, vcc, 0, v77, vcc\n\t"                                                     \
-      "v_addc_co_u32_e64 v77, s[62:63], v77, 0, s[66:67]\n\t"                                           \
-      "v_add_co_u32_dpp v84, vcc, v88, v89 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"      \
-      "v_addc_co_u32_e32 v85, vcc, 0, v85, vcc\n\t"                                                     \
-      "v_addc_co_u32_e64 v85, s[62:63], v85, 0, s[70:71]\n\t"
+      "v_addc_co_u32_e64 v65, s[62:63], v70, 0, s[64:65]\n\t"                                           \
+      "v_addc_co_u32_e64 v73, s[62:63], v70, 0, s[68:69]\n\t"                                           \
+      "v_mov_b32_dpp v78, v68 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"                   \
+      "v_readfirstlane_b32 s72, v76\n\t"                                                                \
+      "v_writelane_b32 v78, s72, 63\n\t"                                                                \
+      "v_add_co_u32_e32 v64, vcc, v78, v69\n\t"                                                         \
+      "v_addc_co_u32_e32 v65, vcc, 0, v65, vcc\n\t"                                                     \
+      "v_addc_co_u32_e64 v65, s[62:63], v65, 0, s[66:67]\n\t"                                           \
+      "v_add_co_u32_dpp v72, vcc, v76, v77 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"      \
+      "v_addc_co_u32_e32 v73, vcc, 0, v73, vcc\n\t"                                                     \
+      "v_addc_co_u32_e64 v73, s[62:63], v73, 0, s[70:71]\n\t"
 
 __device__ __forceinline__ void mont_core_128(uint32_t (&tl)[2], uint32_t (&th)[2], uint32_t a0, uint32_t a1, uint32_t b0,
                                               uint32_t b1, uint32_t n0, uint32_t n1, uint32_t ninv) {
   asm volatile(
-      "v_mov_b32 v76, 0\n\t"
-      "v_mov_b32 v77, 0\n\t"
-      "v_mov_b32 v84, 0\n\t"
-      "v_mov_b32 v85, 0\n\t"
-      "v_mov_b32 v82, 0\n\t"
+      "v_mov_b32 v64, 0\n\t"
+      "v_mov_b32 v65, 0\n\t"
+      "v_mov_b32 v72, 0\n\t"
+      "v_mov_b32 v73, 0\n\t"
+      "v_mov_b32 v70, 0\n\t"
       "s_mov_b32 s60, 0\n\t"
       "v_readlane_b32 s61, %6, s60\n"              // b limb 0
       "1:\n\t"                                     // steps 0..63: b limbs of the lower group
@@ -210,13 +210,13 @@ __device__ __forceinline__ void mont_core_128(uint32_t (&tl)[2], uint32_t (&th)[
       ".rept 4\n\t" ZKE_MONT128_STEP("%7") ".endr\n\t"
       "s_cmp_lt_u32 s60, 128\n\t"
       "s_cbranch_scc1 2b\n\t"
-      "v_mov_b32 %0, v76\n\t"
-      "v_mov_b32 %1, v77\n\t"
-      "v_mov_b32 %2, v84\n\t"
-      "v_mov_b32 %3, v85"
+      "v_mov_b32 %0, v64\n\t"
+      "v_mov_b32 %1, v65\n\t"
+      "v_mov_b32 %2, v72\n\t"
+      "v_mov_b32 %3, v73"
       : "=&v"(tl[0]), "=&v"(th[0]), "=&v"(tl[1]), "=&v"(th[1])
       : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "v"(n0), "v"(n1), "s"(__builtin_amdgcn_readfirstlane(ninv))
-      : "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90",
+      : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78",
         "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "vcc", "scc");
 }
 #undef ZKE_MONT128_STEP

@@ -139,7 +139,7 @@ __device__ __forceinline__ void rsa_wave(const RsaJob* __restrict__ jobs, uint32
 
 // One kernel for both containers: a wave picks the one-limb-per-lane (<= 2048 bits) or two-limbs-per-lane path
 // from its job's modulus size (wave-uniform branch).
-__global__ __launch_bounds__(256) void rsa_verify_kernel(const RsaJob* __restrict__ jobs, uint32_t n,
+__global__ __launch_bounds__(256, 6) void rsa_verify_kernel(const RsaJob* __restrict__ jobs, uint32_t n,
                                                          const uint8_t* __restrict__ hash_base, size_t hash_stride,
                                                          uint32_t* __restrict__ ok_out, uint8_t* __restrict__ em_out,
                                                          KeyCacheEntry* cache, const uint8_t* __restrict__ key_hash_base,
