@@ -47,6 +47,7 @@ struct DevBuf {
 struct RegisteredDfa {
   bool valid = false;       // both blobs deserialise (dense::DFA::from_bytes would succeed)
   size_t lds_bytes = 0;     // repacked fwd + rev tables
+  uint32_t idle = 0xFFFFFFFFu;   // forward automaton's idle state (dfa_idle_state)
   DevBuf blob;              // the repacked tables
   DevBuf dev;               // RegexDev image
 };
@@ -80,6 +81,8 @@ struct zke_engine {
   DevBuf pending; // device counter: e-mails that need another signature round
   std::vector<RegisteredDfa*> dfas;
   int sha_tile = SHA_TILE;
+  int dfa_wave = 1;                 // regex parts: one e-mail per wave with a chunk map (ZKE_DFA_WAVE=0: one e-mail per lane)
+  size_t dfa_wave_lds_attr = 0;
   int sha_pair = -1;                // two-wave SHA-256 kernel: -1 by launch size, 0 never, 1 always (ZKE_SHA_PAIR)
   bool front_attr_set = false;
   bool wave_parse = true;           // front end: one e-mail per wavefront (parse.hip.h); ZKE_LANE_PARSE=1 selects the
@@ -195,6 +198,7 @@ int zke_engine_create(const zke_options* opt, zke_engine** out) {
   if (getenv("ZKE_LANE_PARSE")) e->wave_parse = false;
   if (const char* st = getenv("ZKE_SHA_TILE")) e->sha_tile = atoi(st);
   if (const char* sp = getenv("ZKE_SHA_PAIR")) e->sha_pair = atoi(sp);
+  if (const char* dw = getenv("ZKE_DFA_WAVE")) e->dfa_wave = atoi(dw);
   if (getenv("ZKE_DEBUG_SKIP_RSA")) e->debug_skip_rsa = 1;
   if (getenv("ZKE_DEBUG_SKIP_ED")) e->debug_skip_ed = 1;
   if (getenv("ZKE_NO_FUSE_CANON")) e->fuse_canon = 0;

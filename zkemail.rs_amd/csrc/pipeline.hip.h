@@ -133,7 +133,16 @@ int run_device_pipeline(zke_engine* e, const zke_batch* in, uint64_t raw_total, 
         HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&dfa_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         e->dfa_lds_attr = lds;
       }
-      hipLaunchKernelGGL(dfa_kernel, dim3((n + 255) / 256), dim3(256), lds, s, da);
+      da.idle = (rd && rd->valid) ? rd->idle : 0xFFFFFFFFu;
+      if (e->dfa_wave) {
+        if (lds > e->dfa_wave_lds_attr) {
+          HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&dfa_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          e->dfa_wave_lds_attr = lds;
+        }
+        hipLaunchKernelGGL(dfa_wave_kernel, dim3((n + 3) / 4), dim3(256), lds, s, da);      // one e-mail per wave
+      } else {
+        hipLaunchKernelGGL(dfa_kernel, dim3((n + 255) / 256), dim3(256), lds, s, da);        // one e-mail per lane
+      }
     }
     RegexFinArgs rf{B2, e->parts.as<PartRes>(), in->n_header_parts, in->n_body_parts};
     hipLaunchKernelGGL(regex_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, s, rf);
@@ -162,7 +171,38 @@ uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) 
 struct HostDfa {
   DfaDev d{};
   std::vector<uint32_t> table;
+  uint32_t idle = 0xFFFFFFFFu;     // see dfa_idle_state
 };
+
+// The state an unanchored search idles in between matches: among the Start::Text state and the states most of its
+// bytes lead to (two hops), the ordinary state (not dead / quit / match) with the most self-loops, if more than half
+// of the byte values stay in it.  Only a hint for dfa_wave_kernel's chunk map: any answer is correct, a good one is fast.
+uint32_t dfa_idle_state(const HostDfa& h) {
+  const DfaDev& d = h.d;
+  if (d.start_kind == 2 || h.table.empty()) return 0xFFFFFFFFu;
+  auto ordinary = [&](uint32_t s) { return s != 0 && s != d.quit_id && !(d.min_match && d.min_match <= s && s <= d.max_match); };
+  auto target = [&](uint32_t s, uint32_t byte) { return h.table[s + d.classes[byte]]; };
+  auto majority = [&](uint32_t s) {
+    uint32_t best = s, bestn = 0;
+    for (uint32_t x = 0; x < 256; x++) {
+      const uint32_t t = target(s, x);
+      uint32_t cnt = 0;
+      for (uint32_t y = 0; y < 256; y++) cnt += target(s, y) == t;
+      if (cnt > bestn) { bestn = cnt; best = t; }
+    }
+    return best;
+  };
+  uint32_t cand[3];
+  cand[0] = d.starts[2]; cand[1] = majority(cand[0]); cand[2] = majority(cand[1]);
+  uint32_t idle = 0xFFFFFFFFu, bestn = 127;
+  for (uint32_t c : cand) {
+    if (!ordinary(c)) continue;
+    uint32_t loops = 0;
+    for (uint32_t y = 0; y < 256; y++) loops += target(c, y) == c;
+    if (loops > bestn) { bestn = loops; idle = c; }
+  }
+  return idle;
+}
 
 // dense::DFA::from_bytes restated: structure, sizes and the id validity checks.  false = would not deserialise.
 bool parse_dfa_blob(const uint8_t* b, size_t n, HostDfa& h) {
@@ -265,6 +305,7 @@ int zke_dfa_register(zke_engine* e, const uint8_t* fwd, size_t fwd_len, const ui
     auto packed = [](const HostDfa& h) { return (((size_t)h.d.table_len * (h.d.wide ? 4 : 2)) + 15) & ~(size_t)15; };
     const size_t fb = packed(hf), rb = packed(hr);
     rd->lds_bytes = fb + rb;
+    rd->idle = dfa_idle_state(hf);
     int r = 0;
     if ((r = rd->blob.ensure(fb + rb + 64)) || (r = rd->dev.ensure(sizeof(RegexDev)))) { delete rd; return fail(e, r, "hipMalloc"); }
     std::vector<uint8_t> img(fb + rb + 64, 0);

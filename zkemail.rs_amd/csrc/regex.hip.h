@@ -110,19 +110,42 @@ __device__ __forceinline__ bool dfa_start(const DfaLds& d, bool anchored, bool h
 
 typedef uint4 __attribute__((aligned(1))) uint4_u1;
 
+// Chunk map of one haystack for the wave-per-e-mail kernel: the haystack is cut into 64 chunks of C bytes, and bit l
+// of `clean` says that a walk of chunk l that ENTERS in state X also LEAVES in state X and meets no match, dead or
+// quit state on the way (64 lanes establish that in parallel, one chunk each).  A forward search that stands at a
+// chunk boundary in state X with no match pending can therefore pass over every following clean chunk at once —
+// exactly, whatever X is.  (X is the state the unanchored search idles in between matches, so in ordinary text
+// almost every chunk is clean and the serial walk shrinks to the chunks around the matches.)
+struct DfaAccel { uint64_t clean; uint32_t C, X; bool on; };
+
 // dfa/search.rs find_fwd (leftmost, earliest = false).  1 match, 0 none, -1 quit
 __device__ __forceinline__ int dfa_find_fwd(const DfaLds& d, const uint8_t* hay, uint32_t hlen, uint32_t start, uint32_t end,
-                                            uint32_t& mend) {
+                                            uint32_t& mend, const DfaAccel& acc = DfaAccel{0, 0, 0, false}) {
   if (start > end) return 0;
   uint32_t sid;
   if (!dfa_start(d, false, start > 0, start > 0 ? hay[start - 1] : 0, sid)) return -1;
   int have = 0;
   uint32_t at = start;
   while (at < end) {
+    uint32_t lim = end;
+    if (acc.on) {
+      const uint32_t l = at / acc.C;
+      if (!have && sid == acc.X && at == l * acc.C) {
+        const uint64_t dirty = l < 64 ? (~acc.clean >> l) : 0ull;
+        const uint32_t skip = dirty ? (uint32_t)__builtin_ctzll(dirty) : 64u - l;
+        if (skip) {
+          const uint64_t to = (uint64_t)(l + skip) * acc.C;
+          at = to < end ? (uint32_t)to : end;
+          continue;
+        }
+      }
+      const uint64_t nb_end = (uint64_t)(l + 1) * acc.C;          // stop at the next chunk boundary: the test above runs there
+      if (nb_end < lim) lim = (uint32_t)nb_end;
+    }
     // 16 haystack bytes per load (the buffers carry 16 bytes of slack), walked from registers
     const uint4 v = *(const uint4_u1*)(hay + at);
     const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
-    const uint32_t nb = end - at < 16 ? end - at : 16;
+    const uint32_t nb = lim - at < 16 ? lim - at : 16;
 #pragma unroll
     for (int j = 0; j < 16; j++) {
       if ((uint32_t)j < nb) {
@@ -177,22 +200,22 @@ __device__ __forceinline__ bool is_char_boundary(const uint8_t* hay, uint32_t hl
 }
 // Automaton::try_search_fwd incl. util::empty::skip_splits_fwd
 __device__ __forceinline__ int dfa_search_fwd(const DfaLds& d, const uint8_t* hay, uint32_t hlen, uint32_t start, uint32_t end,
-                                              uint32_t& mend) {
-  int r = dfa_find_fwd(d, hay, hlen, start, end, mend);
+                                              uint32_t& mend, const DfaAccel& acc = DfaAccel{0, 0, 0, false}) {
+  int r = dfa_find_fwd(d, hay, hlen, start, end, mend, acc);
   if (r <= 0) return r;
   if (!(d.has_empty && d.is_utf8)) return 1;
   while (!is_char_boundary(hay, hlen, mend)) {
     start++;
-    r = dfa_find_fwd(d, hay, hlen, start, end, mend);
+    r = dfa_find_fwd(d, hay, hlen, start, end, mend, acc);
     if (r <= 0) return r;
   }
   return 1;
 }
 // dfa::regex::Regex::try_search
 __device__ __forceinline__ int regex_search(const DfaLds& f, const DfaLds& rv, const uint8_t* hay, uint32_t hlen, uint32_t start,
-                                            uint32_t end, uint32_t& ms, uint32_t& me) {
+                                            uint32_t end, uint32_t& ms, uint32_t& me, const DfaAccel& acc = DfaAccel{0, 0, 0, false}) {
   uint32_t e;
-  int r = dfa_search_fwd(f, hay, hlen, start, end, e);
+  int r = dfa_search_fwd(f, hay, hlen, start, end, e, acc);
   if (r <= 0) return r;
   me = e;
   if (start == e) { ms = e; return 1; }
@@ -248,14 +271,12 @@ struct DfaArgs {
   const uint32_t* cap_off; const uint32_t* cap_str_off; const uint8_t* cap_blob;
   PartRes* out;                     // [n * P]
   uint32_t lds_tables;              // 1: both tables fit the dynamic LDS allocation
+  uint32_t idle;                    // dfa_wave_kernel: the forward automaton's idle state (host-chosen; ~0: none, plain serial search)
 };
 
-// blockDim = 256; one e-mail per lane.  Dynamic LDS: fwd table | rev table | 4 x 256-byte maps.
-__global__ __launch_bounds__(256) void dfa_kernel(DfaArgs A) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t dlds[];
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+// stage both automata of the part in the block's dynamic LDS (all threads of the block take part)
+__device__ __forceinline__ bool dfa_stage(const DfaArgs& A, uint8_t* dlds, DfaLds& F, DfaLds& Rv) {
   const RegexDev* re = A.re;
-  DfaLds F{}, Rv{};
   const bool valid = re && re->fwd.valid && re->rev.valid;
   if (valid) {
     const DfaDev* dv[2] = {&re->fwd, &re->rev};
@@ -287,6 +308,65 @@ __global__ __launch_bounds__(256) void dfa_kernel(DfaArgs A) {
     }
   }
   __syncthreads();
+  return valid;
+}
+
+// process_regex_parts for one (e-mail, part): find_iter, exactly one match, captures contained (core/src/regex.rs:35-46)
+__device__ __forceinline__ PartRes dfa_part(const DfaArgs& A, const DfaLds& F, const DfaLds& Rv, uint32_t i, const uint8_t* hay,
+                                            uint32_t hlen, const DfaAccel& acc) {
+  PartRes pr{0, 0, 0, 0};
+  // util::iter::Searcher: non-overlapping; an empty match abutting the previous end restarts one byte on
+  uint32_t start = 0, count = 0, last_end = 0, fs = 0, fe = 0;
+  bool have_last = false;
+  int bad = 0;
+  for (;;) {
+    uint32_t ms, me;
+    int r = regex_search(F, Rv, hay, hlen, start, hlen, ms, me, acc);
+    if (r < 0) { bad = 1; break; }
+    if (r == 0) break;
+    if (ms == me && have_last && me == last_end) {
+      start += 1;
+      r = regex_search(F, Rv, hay, hlen, start, hlen, ms, me, acc);
+      if (r < 0) { bad = 1; break; }
+      if (r == 0) break;
+    }
+    if (count == 0) { fs = ms; fe = me; }
+    count++;
+    if (count >= 2) break;                     // "exactly one" is already decided
+    start = me; have_last = true; last_end = me;
+  }
+  pr.count = count; pr.start = fs; pr.end = fe; pr.code = 0;
+  if (bad) { pr.code = ZKE_D_RE_QUIT; pr.count = 0; pr.start = 0; pr.end = 0; }
+  else if (count != 1) pr.code = ZKE_D_RE_MATCH_COUNT;             // core/src/regex.rs:37
+  else if (A.cap_off) {
+    const uint32_t c0 = A.cap_off[(size_t)i * A.P + A.part], c1 = A.cap_off[(size_t)i * A.P + A.part + 1];
+    const uint8_t* m = hay + fs; const uint32_t ml = fe - fs;
+    int mvalid = -1;
+    for (uint32_t c = c0; c < c1 && !pr.code; c++) {
+      const uint8_t* cs = A.cap_blob + A.cap_str_off[c];
+      const uint32_t cl = A.cap_str_off[c + 1] - A.cap_str_off[c];
+      const uint8_t fffd[3] = {0xEF, 0xBF, 0xBD};
+      if (contains_bytes(cs, cl, fffd, 3)) {
+        if (mvalid < 0) mvalid = utf8_valid(m, ml) ? 1 : 0;
+        if (!mvalid) { pr.code = ZKE_D_U_CAPTURE_FFFD; break; }
+      }
+      if (!contains_bytes(m, ml, cs, cl)) pr.code = ZKE_D_RE_CAPTURE_MISSING;   // core/src/regex.rs:43-46
+    }
+  }
+  return pr;
+}
+
+__device__ __forceinline__ void dfa_haystack(const DfaArgs& A, uint32_t i, const EmailMeta* M, const uint8_t*& hay, uint32_t& hlen) {
+  if (A.is_body) { hay = A.clean + A.clean_off[i]; hlen = M->hashed_len; }
+  else { hay = (M->reuse ? A.scratch_v + A.scratch_v_off[i] : A.b.scratch + A.b.scratch_off[i]); hlen = M->preimage_len; }
+}
+
+// blockDim = 256; one e-mail per lane.  Dynamic LDS: fwd table | rev table | 4 x 256-byte maps.
+__global__ __launch_bounds__(256) void dfa_kernel(DfaArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t dlds[];
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  DfaLds F{}, Rv{};
+  const bool valid = dfa_stage(A, dlds, F, Rv);
   if (i >= A.b.n) return;
   const EmailMeta* M = A.b.meta + i;
   PartRes pr{PART_SKIPPED, 0, 0, 0};
@@ -294,53 +374,65 @@ __global__ __launch_bounds__(256) void dfa_kernel(DfaArgs A) {
     if (!valid) {
       pr.code = PART_DECODE_FAIL;
     } else {
-      const uint64_t r0 = A.b.raw_off[i];
-      const uint32_t raw_len = (uint32_t)(A.b.raw_off[i + 1] - r0);
       const uint8_t* hay; uint32_t hlen;
-      if (A.is_body) { hay = A.clean + A.clean_off[i]; hlen = M->hashed_len; }
-      else { hay = (M->reuse ? A.scratch_v + A.scratch_v_off[i] : A.b.scratch + A.b.scratch_off[i]); hlen = M->preimage_len; }
-      (void)raw_len;
-      // util::iter::Searcher: non-overlapping; an empty match abutting the previous end restarts one byte on
-      uint32_t start = 0, count = 0, last_end = 0, fs = 0, fe = 0;
-      bool have_last = false;
-      int bad = 0;
-      for (;;) {
-        uint32_t ms, me;
-        int r = regex_search(F, Rv, hay, hlen, start, hlen, ms, me);
-        if (r < 0) { bad = 1; break; }
-        if (r == 0) break;
-        if (ms == me && have_last && me == last_end) {
-          start += 1;
-          r = regex_search(F, Rv, hay, hlen, start, hlen, ms, me);
-          if (r < 0) { bad = 1; break; }
-          if (r == 0) break;
-        }
-        if (count == 0) { fs = ms; fe = me; }
-        count++;
-        if (count >= 2) break;                     // "exactly one" is already decided
-        start = me; have_last = true; last_end = me;
-      }
-      pr.count = count; pr.start = fs; pr.end = fe; pr.code = 0;
-      if (bad) { pr.code = ZKE_D_RE_QUIT; pr.count = 0; pr.start = 0; pr.end = 0; }
-      else if (count != 1) pr.code = ZKE_D_RE_MATCH_COUNT;             // core/src/regex.rs:37
-      else if (A.cap_off) {
-        const uint32_t c0 = A.cap_off[(size_t)i * A.P + A.part], c1 = A.cap_off[(size_t)i * A.P + A.part + 1];
-        const uint8_t* m = hay + fs; const uint32_t ml = fe - fs;
-        int mvalid = -1;
-        for (uint32_t c = c0; c < c1 && !pr.code; c++) {
-          const uint8_t* cs = A.cap_blob + A.cap_str_off[c];
-          const uint32_t cl = A.cap_str_off[c + 1] - A.cap_str_off[c];
-          const uint8_t fffd[3] = {0xEF, 0xBF, 0xBD};
-          if (contains_bytes(cs, cl, fffd, 3)) {
-            if (mvalid < 0) mvalid = utf8_valid(m, ml) ? 1 : 0;
-            if (!mvalid) { pr.code = ZKE_D_U_CAPTURE_FFFD; break; }
-          }
-          if (!contains_bytes(m, ml, cs, cl)) pr.code = ZKE_D_RE_CAPTURE_MISSING;   // core/src/regex.rs:43-46
-        }
-      }
+      dfa_haystack(A, i, M, hay, hlen);
+      pr = dfa_part(A, F, Rv, i, hay, hlen, DfaAccel{0, 0, 0, false});
     }
   }
   A.out[(size_t)i * A.P + A.part] = pr;
+}
+
+// One e-mail per WAVE (blockDim = 256: four e-mails share the staged tables).  A DFA walk is a serial chain, but
+// where the chain can be cut is knowable in parallel: the 64 lanes first walk one chunk of the haystack each from
+// the automaton's idle state `A.idle` and report which chunks are "clean" (DfaAccel); the exact search that follows
+// — the same code as the lane-per-e-mail kernel, run wave-uniformly — then steps over runs of clean chunks and walks
+// only the chunks around the matches.  4 KB bodies: 64 dependent steps in the parallel pass + a few hundred serial
+// ones instead of ~4 100.
+__global__ __launch_bounds__(256) void dfa_wave_kernel(DfaArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t dlds[];
+  const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  DfaLds F{}, Rv{};
+  const bool valid = dfa_stage(A, dlds, F, Rv);
+  if (i >= A.b.n) return;
+  const EmailMeta* M = A.b.meta + i;
+  PartRes pr{PART_SKIPPED, 0, 0, 0};
+  if (M->state == ST_CAND) {
+    if (!valid) {
+      pr.code = PART_DECODE_FAIL;
+    } else {
+      const uint8_t* hay; uint32_t hlen;
+      dfa_haystack(A, i, M, hay, hlen);
+      DfaAccel acc{0, 0, 0, false};
+      const uint32_t X = A.idle;
+      if (X != 0xFFFFFFFFu && hlen >= 256) {
+        // chunk size: a multiple of 16 (the walk loads 16 bytes at a time), 64 chunks cover the haystack
+        const uint32_t C = ((hlen + 63) / 64 + 15) & ~15u;
+        const uint32_t lo = (uint32_t)lane * C;
+        bool clean = true;
+        if (lo < hlen) {
+          const uint32_t hi = lo + C < hlen ? lo + C : hlen;
+          uint32_t sid = X;
+          for (uint32_t at = lo; at < hi && clean; at += 16) {
+            const uint4 v = *(const uint4_u1*)(hay + at);
+            const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+            const uint32_t nb = hi - at < 16 ? hi - at : 16;
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+              if ((uint32_t)j < nb) {
+                sid = dfa_tr(F, sid, F.classes[(wv[j >> 2] >> (8 * (j & 3))) & 0xff]);
+                if (sid <= F.sp_max && (dfa_is_match(F, sid) || sid == 0 || dfa_is_quit(F, sid))) clean = false;
+              }
+            }
+          }
+          clean = clean && sid == X;
+        }
+        acc.clean = __ballot(clean); acc.C = C; acc.X = X; acc.on = true;
+      }
+      pr = dfa_part(A, F, Rv, i, hay, hlen, acc);
+    }
+  }
+  if (lane == 0) A.out[(size_t)i * A.P + A.part] = pr;
 }
 
 // ---- verdict of the regex stage (thread per e-mail) ------------------------------------------
