@@ -98,6 +98,64 @@ def test_dfa_search_semantics_parity(engine, oracle):
                 assert (int(got[i]["match_start"]), int(got[i]["match_end"])) == spans[0], (pat, hay)
 
 
+def test_long_haystacks_chunk_map_parity(engine, oracle):
+    """dfa_wave_kernel cuts haystacks of 256+ bytes into 64 chunks and steps over the ones an idle-state walk
+    passes unchanged: bodies of 300 B .. 9 KB with zero, one or two matches placed everywhere relative to the chunk
+    boundaries (straddling them, at the very start, at the very end), for unanchored, class-heavy, alternation,
+    anchored and dot-star patterns.  Spans are checked against the oracle and against Python's `re`."""
+    pats = [r"ZKE-ORDER-([0-9]{8});", r"tok=([a-f0-9]+)!", r"(cat|dog|bird)s? sat", r"^first line", r"end of it$",
+            r"a[^\r\n]*z", r"[A-Z]{3}-[0-9]{2}", r"x+y", r"needle"]
+    k0 = synth.load_keys()["rsa2048_00"]
+    hdrs = synth.std_headers(np.random.default_rng(1), 1, "example.com")
+    rng = np.random.default_rng(77)
+    fill = np.frombuffer(b"bcdefghijklmnopqrstuvw .,;-0123456789", np.uint8)
+    inserts = [b"ZKE-ORDER-12345678;", b"tok=deadbeef01!", b"cats sat", b"dog sat", b"ABC-42", b"xxxxy", b"needle", b"a----z",
+               b"ZKE-ORDER-1234567;", b"tok=!", b"ZKE-ORDER-"]
+    hays = []
+    for hlen in (300, 511, 1024, 1500, 4096, 4100, 9000):
+        C = ((hlen + 63) // 64 + 15) & ~15
+        for k in range(14):
+            body = bytearray(fill[rng.integers(0, len(fill), hlen)].tobytes())
+            twice = inserts[int(rng.integers(0, 8))]                       # one marker that may appear more than once
+            for _ in range(int(rng.integers(0, 6))):
+                ins = twice if rng.random() < 0.5 else inserts[int(rng.integers(0, len(inserts)))]
+                # half of the time exactly on / across a chunk boundary
+                if rng.random() < 0.5:
+                    pos = int(rng.integers(1, max(2, hlen // C))) * C - int(rng.integers(0, len(ins) + 1))
+                else:
+                    pos = int(rng.integers(0, hlen - len(ins)))
+                pos = max(0, min(pos, hlen - len(ins)))
+                body[pos:pos + len(ins)] = ins
+            if k == 0:
+                body[:10] = b"first line"
+            if k == 1:
+                body[-9:] = b"end of it"
+            if k == 2:
+                body[:19] = b"ZKE-ORDER-00000001;"
+            if k == 3:
+                body[-19:] = b"ZKE-ORDER-99999999;"
+            hays.append(bytes(body).replace(b"\r", b"-").replace(b"\n", b"-") + b"\r\n")
+    emails = []
+    for hay in hays:
+        raw, it = synth.sign_email(hdrs, hay, k0, synth.SignSpec(header_canon="simple", body_canon="simple"))
+        assert it["canon_body"] == hay
+        emails.append(A.Email("example.com", raw, A.PublicKey(k0.pkcs1_der)))
+    seen = {0: 0, 1: 0, 2: 0}
+    for pat in pats:
+        d = rc.create_dfa(pat)
+        ins = [A.EmailWithRegex(e, A.RegexInfo(None, [A.CompiledRegex(d, [])])) for e in emails]
+        got = engine.verify_batch(engine.pack_with_regex(ins))
+        exp = oracle.verify_batch(oracle.pack_with_regex(ins), threads=4)
+        assert_records_equal(got, exp, None, pat)
+        for i, hay in enumerate(hays):
+            spans = rust_find_iter(pat, hay)
+            assert int(got[i]["match_count"]) == min(len(spans), 2), (pat, i)
+            seen[min(len(spans), 2)] += 1
+            if spans:
+                assert (int(got[i]["match_start"]), int(got[i]["match_end"])) == spans[0], (pat, i)
+    assert min(seen.values()) >= 15, seen
+
+
 def test_large_dfa_tables_and_utf8_flags(engine, oracle):
     """A DFA whose tables exceed the u16 range / the LDS budget falls back to u32 entries read from HBM;
     is_utf8 + has_empty exercises skip_splits_fwd on the device."""

@@ -203,9 +203,11 @@ def test_lane_front_end_variant_parity(tmp_path):
         tr.test_first_signature_canonicalisation_parity(eng, orc)
         tr.test_regex_workload_parity(eng, orc, dict(n=96, body_len=4096, rsa_bits=4096, n_keys=8, n_header_parts=2,
                                                     n_body_parts=2, qp_frac=0.05, fail_frac=0.3, seed=5))
+        tr.test_long_haystacks_chunk_map_parity(eng, orc)
         print("lane front end ok")
     """)
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ZKE_LANE_PARSE="1"), capture_output=True, text=True,
+    # ... and the lane-per-e-mail DFA kernel (the default is the wave-per-e-mail one)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ZKE_LANE_PARSE="1", ZKE_DFA_WAVE="0"), capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0 and "lane front end ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
