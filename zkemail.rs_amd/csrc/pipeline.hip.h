@@ -114,34 +114,54 @@ int run_device_pipeline(zke_engine* e, const zke_batch* in, uint64_t raw_total, 
     QpArgs qa{B2, B.meta, e->clean.as<uint8_t>(), clean_off, B.scratch, B.scratch_off};
     hipLaunchKernelGGL(qp_kernel, dim3(n), dim3(64), 0, s, qa);    // circuits.rs:37 runs whether or not body parts exist
     tm.mark();
-    for (uint32_t p = 0; p < P; p++) {
-      const bool is_body = p >= in->n_header_parts;
+    auto part_dfa = [&](uint32_t p) -> const RegisteredDfa* {
       // part ids are host-visible only in host mode; zke_verify_batch_device receives them as host arrays too
-      const uint32_t id = is_body ? e->host_body_ids[p - in->n_header_parts] : e->host_hdr_ids[p];
-      const RegisteredDfa* rd = id < e->dfas.size() ? e->dfas[id] : nullptr;
-      DfaArgs da{};
-      da.b = B2; da.re = (rd && rd->valid) ? rd->dev.as<RegexDev>() : nullptr;
-      da.part = p; da.P = P; da.is_body = is_body ? 1 : 0;
-      da.scratch_v = B.scratch; da.scratch_v_off = B.scratch_off;
-      da.clean = e->clean.as<uint8_t>(); da.clean_off = clean_off;
-      da.cap_off = in->cap_off; da.cap_str_off = in->cap_str_off; da.cap_blob = in->cap_blob;
-      da.out = e->parts.as<PartRes>();
-      size_t lds = 1024;
-      da.lds_tables = 0;
-      if (rd && rd->valid && rd->lds_bytes + 1024 <= 150 * 1024) { da.lds_tables = 1; lds = rd->lds_bytes + 1024; }
-      if (lds > e->dfa_lds_attr) {
-        HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&dfa_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        e->dfa_lds_attr = lds;
-      }
-      da.idle = (rd && rd->valid) ? rd->idle : 0xFFFFFFFFu;
-      if (e->dfa_wave) {
+      const uint32_t id = p >= in->n_header_parts ? e->host_body_ids[p - in->n_header_parts] : e->host_hdr_ids[p];
+      return id < e->dfas.size() ? e->dfas[id] : nullptr;
+    };
+    DfaArgs base{};
+    base.b = B2; base.P = P;
+    base.scratch_v = B.scratch; base.scratch_v_off = B.scratch_off;
+    base.clean = e->clean.as<uint8_t>(); base.clean_off = clean_off;
+    base.cap_off = in->cap_off; base.cap_str_off = in->cap_str_off; base.cap_blob = in->cap_blob;
+    base.out = e->parts.as<PartRes>();
+    auto part_lds = [&](const RegisteredDfa* rd, uint32_t& in_lds) -> size_t {
+      in_lds = 0;
+      if (rd && rd->valid && rd->lds_bytes + 1024 <= 150 * 1024) { in_lds = 1; return rd->lds_bytes + 1024; }
+      return 1024;
+    };
+    if (e->dfa_wave) {
+      // one e-mail per wave; up to DFA_MULTI_MAX parts per launch (grid.y)
+      for (uint32_t p0 = 0; p0 < P; p0 += DFA_MULTI_MAX) {
+        const uint32_t np = std::min<uint32_t>(DFA_MULTI_MAX, P - p0);
+        DfaMultiArgs ma{};
+        ma.common = base; ma.part0 = p0; ma.n_header_parts = in->n_header_parts;
+        size_t lds = 1024;
+        for (uint32_t k = 0; k < np; k++) {
+          const RegisteredDfa* rd = part_dfa(p0 + k);
+          ma.re[k] = (rd && rd->valid) ? rd->dev.as<RegexDev>() : nullptr;
+          lds = std::max(lds, part_lds(rd, ma.lds_tables[k]));
+          ma.idle[k] = (rd && rd->valid) ? rd->idle : 0xFFFFFFFFu;
+        }
         if (lds > e->dfa_wave_lds_attr) {
           HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&dfa_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
           e->dfa_wave_lds_attr = lds;
         }
-        hipLaunchKernelGGL(dfa_wave_kernel, dim3((n + 3) / 4), dim3(256), lds, s, da);      // one e-mail per wave
-      } else {
-        hipLaunchKernelGGL(dfa_kernel, dim3((n + 255) / 256), dim3(256), lds, s, da);        // one e-mail per lane
+        hipLaunchKernelGGL(dfa_wave_kernel, dim3((n + 3) / 4, np), dim3(256), lds, s, ma);
+      }
+    } else {
+      for (uint32_t p = 0; p < P; p++) {                       // one e-mail per lane, one launch per part
+        const RegisteredDfa* rd = part_dfa(p);
+        DfaArgs da = base;
+        da.re = (rd && rd->valid) ? rd->dev.as<RegexDev>() : nullptr;
+        da.part = p; da.is_body = p >= in->n_header_parts ? 1 : 0;
+        const size_t lds = part_lds(rd, da.lds_tables);
+        if (lds > e->dfa_lds_attr) {
+          HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&dfa_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          e->dfa_lds_attr = lds;
+        }
+        da.idle = 0xFFFFFFFFu;
+        hipLaunchKernelGGL(dfa_kernel, dim3((n + 255) / 256), dim3(256), lds, s, da);
       }
     }
     RegexFinArgs rf{B2, e->parts.as<PartRes>(), in->n_header_parts, in->n_body_parts};

@@ -388,8 +388,24 @@ __global__ __launch_bounds__(256) void dfa_kernel(DfaArgs A) {
 // — the same code as the lane-per-e-mail kernel, run wave-uniformly — then steps over runs of clean chunks and walks
 // only the chunks around the matches.  4 KB bodies: 64 dependent steps in the parallel pass + a few hundred serial
 // ones instead of ~4 100.
-__global__ __launch_bounds__(256) void dfa_wave_kernel(DfaArgs A) {
+// All parts of the batch in one launch: blockIdx.y picks the part (each block stages that part's tables), so the
+// parts' walks overlap instead of queueing behind each other.
+constexpr uint32_t DFA_MULTI_MAX = 8;
+struct DfaMultiArgs {
+  DfaArgs common;                         // part / re / is_body / lds_tables / idle are filled per block from the arrays
+  uint32_t part0;                         // index of the first part of this launch
+  uint32_t n_header_parts;
+  const RegexDev* re[DFA_MULTI_MAX];
+  uint32_t lds_tables[DFA_MULTI_MAX];
+  uint32_t idle[DFA_MULTI_MAX];
+};
+
+__global__ __launch_bounds__(256) void dfa_wave_kernel(DfaMultiArgs MA) {
   extern __shared__ __attribute__((aligned(16))) uint8_t dlds[];
+  DfaArgs A = MA.common;
+  A.part = MA.part0 + blockIdx.y;
+  A.re = MA.re[blockIdx.y]; A.lds_tables = MA.lds_tables[blockIdx.y]; A.idle = MA.idle[blockIdx.y];
+  A.is_body = A.part >= MA.n_header_parts ? 1u : 0u;
   const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   DfaLds F{}, Rv{};
