@@ -3,11 +3,12 @@
 // Call sites in the reference: core/src/email.rs:31-33 (inside verify_email_with_key) and
 // core/src/circuits.rs:34-35 (canonicalize_signed_email).
 //
-// One e-mail per wavefront.  Relaxed canonicalisation is a stream compaction: every lane
-// owns one byte of a 64-byte chunk, the keep / insert-SP decisions are ballots, output
-// offsets are popcounts of the lower lanes, and the next chunk is loaded one step ahead so
-// the single dependent HBM load per step is off the critical path.  Simple canonicalisation
-// moves no bytes: the SHA job points at the raw body with the trailing empty lines cut off.
+// One e-mail per wavefront; normally the wave is the front-end wave of that e-mail (parse.hip.h calls
+// canon_body_wave when it has chosen the candidate signature).  Relaxed canonicalisation is a stream compaction:
+// four consecutive bytes per lane (256 B per step), loads eight steps ahead, keep / insert-SP decisions per byte,
+// output offsets from count-bit ballots, bytes compacted in LDS and stored 16 bytes per lane; the end of the body is
+// settled on the bytes still in LDS.  Simple canonicalisation moves no bytes: the SHA job points at the raw body
+// with the trailing empty lines cut off.
 #pragma once
 #include "parse.hip.h"
 

@@ -13,9 +13,10 @@
 // Execution model.  Control flow is wave-uniform (one e-mail, one parser state); the 64 lanes
 // are used as a 64-byte-wide scanner: each primitive looks at 64 consecutive bytes at once and
 // turns per-byte predicates into 64-bit ballot masks (find first / find last / stream
-// compaction by popcount prefix).  Header fields are small (≈1 KB per e-mail) and are read
-// straight from HBM through L2/L1; the per-e-mail tables (header spans, tag records, the
-// FWS-stripped tag values) live in LDS.
+// compaction by popcount prefix).  The head of the e-mail (3.75 KB: the header block of ordinary mail) is staged
+// in LDS with 16-byte lane-contiguous loads; the per-e-mail tables (header spans, tag records, the FWS-stripped
+// tag values) live in LDS too.  In round 0 the kernel also does the batch's bookkeeping (batch_prologue), and
+// after the parse the same wave canonicalises the body (canon.hip.h) — one launch for the whole front end.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

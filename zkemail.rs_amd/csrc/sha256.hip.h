@@ -15,8 +15,10 @@
 // (lane stride = 4 banks mod 64).  No __syncthreads: a wave's LDS operations execute in
 // order, and no other wave touches its slab.
 //
-// Roofline: integer-VALU bound (about 1.5k VALU per 64-byte block per lane), not HBM
-// bound; DESIGN.md §kernels has the arithmetic.
+// Roofline: integer-VALU bound (about 1.4k VALU per 64-byte block per lane), not HBM
+// bound; DESIGN.md §3 has the arithmetic.  Two kernels: sha256_batch_kernel (one wave per 64 messages, for
+// launches that fill the chip) and sha256_pair_kernel (two waves per 64 messages — message schedule and rounds
+// — for launches whose duration is one wave's chain of compressions; it is the one BASELINE-sized batches use).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
