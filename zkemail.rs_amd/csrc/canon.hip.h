@@ -91,6 +91,47 @@ __device__ __forceinline__ void canon_body_wave(const BatchDev& B, uint32_t i, u
     uint32_t last_in = OOB;                   // last byte of the body
     bool tail_done = false;
     for (uint32_t base0 = 0; base0 < blen; base0 += 256u * RING) {
+      // Whole group clean?  The 2 KB in the ring (8 windows, a dword per lane each) are tested with byte-parallel
+      // arithmetic — no TAB, no SP in front of SP / TAB / CR, no WSP at either edge — and then leave as eight
+      // coalesced dword stores: no LDS, no per-window scalar bookkeeping (ordinary text is almost all such
+      // groups).  The last group of the body always takes the window path below, which settles the body's end.
+      if (base0 + 256u * RING < blen && !is_wsp(prev_last)) {
+        auto eqb = [](uint32_t x, uint32_t c) -> uint32_t {       // 0x80 in every byte of x that equals c (exact)
+          const uint32_t y = x ^ (c * 0x01010101u);
+          return ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu);
+        };
+        uint32_t bad = 0;
+#pragma unroll
+        for (int k = 0; k < RING; k++) {
+          const uint32_t x = q[k];
+          uint32_t up = lane_up(x);                                 // the dword after mine (lane + 1)
+          const uint32_t nfirst = k + 1 < RING ? __builtin_amdgcn_readfirstlane(q[(k + 1) & (RING - 1)]) : 0x41414141u;
+          if (lane == 63) up = nfirst;                              // next window (the group's last byte is tested apart)
+          const uint32_t nx = (x >> 8) | (up << 24);                // byte i+1 under byte i
+          bad |= (eqb(x, 0x20) & (eqb(nx, 0x20) | eqb(nx, 0x09) | eqb(nx, 0x0d))) | eqb(x, 0x09);
+        }
+        const uint32_t glast = __builtin_amdgcn_readlane(q[RING - 1], 63) >> 24;
+        if (!is_wsp(glast) && __ballot(bad != 0) == 0) {
+          if (fill) {                                               // bytes of an earlier, dirty group still in LDS
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t bq = 16u * lane; bq + 16 <= fill; bq += 1024) *(uint4_store_unaligned*)(regB + o + bq) = *(const uint4*)(lds + bq);
+            const uint32_t tb = (fill & ~15u) + lane;
+            if (lane < 16 && tb < fill) regB[o + tb] = lds[tb];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            o += fill; fill = 0;
+          }
+#pragma unroll
+          for (int k = 0; k < RING; k++) {
+            *(u32_unaligned*)(regB + o + 256u * k + 4 * lane) = q[k];
+            q[k] = load4(base0 + 256u * RING + 256u * k + 4 * lane);
+          }
+          o += 256u * RING;
+          prev_last = glast;
+          continue;
+        }
+      }
 #pragma unroll
       for (int k = 0; k < RING; k++) {
         const uint32_t base = base0 + 256u * k;
