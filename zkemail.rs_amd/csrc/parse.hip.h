@@ -409,7 +409,7 @@ __device__ __forceinline__ bool parse_usize_tag(const ParseLds& L, int id, uint6
 
 // ------------------------------------------------------------------ mailparse header split
 // Fills L.hdr; returns the header count or NONE with *perr set.
-__device__ __forceinline__ uint32_t split_headers(ParseLds& L, const Str& raw, uint32_t& perr) {
+__device__ __forceinline__ uint32_t split_headers(ParseLds& L, const Str& raw, uint32_t& perr, uint32_t& hdr_end) {
   Win w; w.wpos = WNONE; w.c = 0;
   const uint32_t len = raw.len;
   uint32_t ix = 0, nh = 0;
@@ -452,15 +452,19 @@ __device__ __forceinline__ uint32_t split_headers(ParseLds& L, const Str& raw, u
     nh++;
     ix = next;
   }
+  hdr_end = ix;                       // where the header list stopped: the empty line, or the end of the input
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   return nh;
 }
 
-// cfdkim get_body: everything after the first CRLFCRLF (empty when there is none)
-__device__ __forceinline__ uint32_t find_body(const Str& raw) {
+// cfdkim get_body: everything after the first CRLFCRLF (empty when there is none).
+// `from`: a position no CRLFCRLF starts in front of.  After split_headers that is hdr_end - 2: bytes p..p+3 =
+// CRLFCRLF make p+2 a line start that begins with CRLF (the LF at p+1 cannot continue a folded line: CR follows),
+// and the header split stops at the first such line start, so p + 2 >= hdr_end.
+__device__ __forceinline__ uint32_t find_body(const Str& raw, uint32_t from) {
   const uint32_t len = raw.len;
-  for (uint32_t base = 0; base + 4 <= len; base += 61) {
+  for (uint32_t base = from; base + 4 <= len; base += 61) {
     const uint32_t c = ldb(raw, base + lane_id());
     const uint64_t r = __ballot(c == '\r'), n = __ballot(c == '\n');
     uint64_t m = r & (n >> 1) & (r >> 2) & (n >> 3) & bits_below(61);
@@ -675,13 +679,14 @@ __global__ __launch_bounds__(64, 3) void parse_kernel(ParseArgs A) {
 
   // ---- mailparse::parse_mail (core/src/email.rs:26)
   uint32_t perr;
-  const uint32_t nh = split_headers(L, raw, perr);
+  uint32_t hdr_end = 0;
+  const uint32_t nh = split_headers(L, raw, perr, hdr_end);
   if (nh == NONE) {
     finish(perr == ZKE_D_U_TOO_MANY_HEADERS ? ZKE_UNSUPPORTED : ZKE_PARSE_FAIL, perr);
     return;
   }
   if (A.debug_stop == 2) return;
-  const uint32_t body_off = find_body(raw);
+  const uint32_t body_off = find_body(raw, hdr_end >= 2 ? hdr_end - 2 : 0);
   if (A.debug_stop == 3) return;
   if (lane == 0) {
     if (A.mode == 0) { R->n_headers = nh; R->body_offset = body_off; }
