@@ -85,12 +85,15 @@ struct BatchDev {
   const EmailMeta* meta_verify; // mode 1 only: the verify pass's meta
 };
 constexpr uint32_t PRE_SLACK = 1024;
-constexpr uint32_t SCR_PER_EMAIL = PRE_SLACK + 64;      // fixed part of an e-mail's scratch slot
+constexpr uint32_t HDR_LDS_ENTRIES = 128;               // header spans kept in LDS; entries 128..255 overflow to the scratch slot
+constexpr uint32_t HDR_OVF_BYTES = (ZKE_MAX_HEADERS - HDR_LDS_ENTRIES) * 16;
+constexpr uint32_t SCR_PER_EMAIL = HDR_OVF_BYTES + PRE_SLACK + 64;      // fixed part of an e-mail's scratch slot
 constexpr uint32_t CLEAN_PER_EMAIL = 32;
 
-// scratch_off[i] = align16(2 * (raw_off[i] - raw_off[0])) + i * SCR_PER_EMAIL   (region A then region B)
+// slot i = [header-span overflow (HDR_OVF_BYTES)] [region A] [region B], at align16(2 * (raw_off[i] - raw_off[0])) + i * SCR_PER_EMAIL;
+// scratch_off[i] is the offset of region A
 // clean_off[i]   = (raw_off[i] - raw_off[0]) + i * CLEAN_PER_EMAIL
-__host__ __device__ inline uint64_t scratch_offset(uint64_t rel, uint32_t i) { return ((2 * rel + 15) & ~15ull) + (uint64_t)i * SCR_PER_EMAIL; }
+__host__ __device__ inline uint64_t scratch_offset(uint64_t rel, uint32_t i) { return ((2 * rel + 15) & ~15ull) + (uint64_t)i * SCR_PER_EMAIL + HDR_OVF_BYTES; }
 __host__ __device__ inline uint64_t clean_offset(uint64_t rel, uint32_t i) { return rel + (uint64_t)i * CLEAN_PER_EMAIL; }
 
 // Round-0 bookkeeping of a batch, done by the front-end kernel itself instead of three tiny launches (an offsets
@@ -277,11 +280,27 @@ __device__ __forceinline__ void emit_header(Out& out, const Str& key, const Str&
 
 // ------------------------------------------------------------------ LDS image of one wave
 struct ParseLds {
-  uint32_t hdr[4 * ZKE_MAX_HEADERS];   // key_start, key_end, val_start, val_end
+  uint32_t hdr[4 * HDR_LDS_ENTRIES];   // key_start, key_end, val_start, val_end of headers 0..127 (hdr_get / hdr_put)
   uint32_t tag[TG_N][4];               // raw_s, raw_e, val_off, val_len (last occurrence wins, as IndexMap::insert)
   uint8_t tagbuf[ZKE_MAX_TAGBUF];      // FWS-stripped tag values
   __attribute__((aligned(16))) uint8_t stage[PARSE_STAGE_BYTES];   // head of the e-mail (header block), copied in 16-byte lanes
 };
+
+// Header span table: 128 entries in LDS (10 KB of LDS per wave would cap a CU at 16 front-end waves; 8 KB lets the
+// register budget decide), the rest — e-mails with more than 128 header fields — in the e-mail's scratch slot.
+// The overflow is written and read back by the same wave: the reads go around L1 (agent-scope atomic loads).
+struct HdrSpan { uint32_t ks, ke, vs, ve; };
+__device__ __forceinline__ void hdr_put(ParseLds& L, uint32_t* ovf, uint32_t x, uint32_t ks, uint32_t ke, uint32_t vs, uint32_t ve) {
+  if (lane_id() != 0) return;
+  uint32_t* p = x < HDR_LDS_ENTRIES ? L.hdr + 4 * x : ovf + 4 * (x - HDR_LDS_ENTRIES);
+  p[0] = ks; p[1] = ke; p[2] = vs; p[3] = ve;
+}
+__device__ __forceinline__ HdrSpan hdr_get(const ParseLds& L, const uint32_t* ovf, uint32_t x) {
+  if (x < HDR_LDS_ENTRIES) return HdrSpan{L.hdr[4 * x], L.hdr[4 * x + 1], L.hdr[4 * x + 2], L.hdr[4 * x + 3]};
+  const uint32_t* p = ovf + 4 * (x - HDR_LDS_ENTRIES);
+  auto ld = [](const uint32_t* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  return HdrSpan{ld(p), ld(p + 1), ld(p + 2), ld(p + 3)};
+}
 
 // strip FWS from v[rs,re) into tagbuf at *tb; returns false on overflow
 __device__ __forceinline__ bool strip_to_lds(ParseLds& L, const Str& v, uint32_t rs, uint32_t re, uint32_t& tb) {
@@ -409,7 +428,7 @@ __device__ __forceinline__ bool parse_usize_tag(const ParseLds& L, int id, uint6
 
 // ------------------------------------------------------------------ mailparse header split
 // Fills L.hdr; returns the header count or NONE with *perr set.
-__device__ __forceinline__ uint32_t split_headers(ParseLds& L, const Str& raw, uint32_t& perr, uint32_t& hdr_end) {
+__device__ __forceinline__ uint32_t split_headers(ParseLds& L, uint32_t* ovf, const Str& raw, uint32_t& perr, uint32_t& hdr_end) {
   Win w; w.wpos = WNONE; w.c = 0;
   const uint32_t len = raw.len;
   uint32_t ix = 0, nh = 0;
@@ -448,7 +467,7 @@ __device__ __forceinline__ uint32_t split_headers(ParseLds& L, const Str& raw, u
       ve = (lastv == NONE) ? vs : lastv + 1;
     }
     if (nh >= ZKE_MAX_HEADERS) { perr = ZKE_D_U_TOO_MANY_HEADERS; return NONE; }
-    if (lane_id() == 0) { L.hdr[4 * nh] = ix; L.hdr[4 * nh + 1] = key_end; L.hdr[4 * nh + 2] = vs; L.hdr[4 * nh + 3] = ve; }
+    hdr_put(L, ovf, nh, ix, key_end, vs, ve);
     nh++;
     ix = next;
   }
@@ -603,7 +622,7 @@ __device__ __forceinline__ void canon_body_wave(const BatchDev& B, uint32_t i, u
 
 __device__ const uint8_t DKIM_NAME[14] = {'D', 'K', 'I', 'M', '-', 'S', 'i', 'g', 'n', 'a', 't', 'u', 'r', 'e'};
 
-__global__ __launch_bounds__(64, 3) void parse_kernel(ParseArgs A) {
+__global__ __launch_bounds__(64, 5) void parse_kernel(ParseArgs A) {
   __shared__ ParseLds L;
   const BatchDev& B = A.b;
   const uint32_t i = blockIdx.x;
@@ -680,7 +699,8 @@ __global__ __launch_bounds__(64, 3) void parse_kernel(ParseArgs A) {
   // ---- mailparse::parse_mail (core/src/email.rs:26)
   uint32_t perr;
   uint32_t hdr_end = 0;
-  const uint32_t nh = split_headers(L, raw, perr, hdr_end);
+  uint32_t* hdr_ovf = (uint32_t*)(regA - HDR_OVF_BYTES);       // in front of region A
+  const uint32_t nh = split_headers(L, hdr_ovf, raw, perr, hdr_end);
   if (nh == NONE) {
     finish(perr == ZKE_D_U_TOO_MANY_HEADERS ? ZKE_UNSUPPORTED : ZKE_PARSE_FAIL, perr);
     return;
@@ -722,7 +742,8 @@ __global__ __launch_bounds__(64, 3) void parse_kernel(ParseArgs A) {
   uint32_t cand_flags = 0;
   uint64_t cand_len_tag = 0;
   for (uint32_t hx = 0; hx < nh; hx++) {
-    const uint32_t ks = L.hdr[4 * hx], ke = L.hdr[4 * hx + 1], vs = L.hdr[4 * hx + 2], ve = L.hdr[4 * hx + 3];
+    const HdrSpan hs = hdr_get(L, hdr_ovf, hx);
+    const uint32_t ks = hs.ks, ke = hs.ke, vs = hs.vs, ve = hs.ve;
     if (!span_ieq(raw, ks, ke - ks, DKIM_NAME, 14)) continue;
     const uint32_t this_ix = sig_ix++;
     if (first_sig_hdr == NONE) first_sig_hdr = hx;
@@ -882,7 +903,8 @@ __global__ __launch_bounds__(64, 3) void parse_kernel(ParseArgs A) {
             if (same) {
               uint32_t found = NONE;
               for (uint32_t x = cur; x-- > 0;) {
-                const uint32_t ks2 = L.hdr[4 * x], ke2 = L.hdr[4 * x + 1];
+                const HdrSpan h2 = hdr_get(L, hdr_ovf, x);
+                const uint32_t ks2 = h2.ks, ke2 = h2.ke;
                 if (span_ieq(raw, ks2, ke2 - ks2, h + st2, e2 - st2)) { found = x; break; }
               }
               cur = (found == NONE) ? 0 : found;
@@ -893,12 +915,13 @@ __global__ __launch_bounds__(64, 3) void parse_kernel(ParseArgs A) {
         }
         uint32_t found = NONE;
         for (uint32_t x = start; x-- > 0;) {
-          const uint32_t ks2 = L.hdr[4 * x], ke2 = L.hdr[4 * x + 1];
+          const HdrSpan h2 = hdr_get(L, hdr_ovf, x);
+          const uint32_t ks2 = h2.ks, ke2 = h2.ke;
           if (span_ieq(raw, ks2, ke2 - ks2, h + st, e - st)) { found = x; break; }
         }
         if (found != NONE) {
-          const uint32_t* sp = L.hdr + 4 * found;
-          emit_header(out, substr(raw, sp[0], sp[1]), substr(raw, sp[2], sp[3]), hrel, true);
+          const HdrSpan sp = hdr_get(L, hdr_ovf, found);
+          emit_header(out, substr(raw, sp.ks, sp.ke), substr(raw, sp.vs, sp.ve), hrel, true);
         }
         st = e + 1;
       }
