@@ -47,7 +47,7 @@ struct CanonArgs { BatchDev b; uint32_t mode; };
 // over in registers: the wave-per-e-mail front end calls this right after it has chosen the candidate signature
 // (no launch boundary, no trip through EmailMeta); the stand-alone kernel below reads them from EmailMeta.
 // `lds`: CANON_LDS_BYTES of 16-byte aligned LDS the wave may overwrite (the front end hands over its staging buffer).
-constexpr uint32_t CANON_LDS_TRASH = 3776, CANON_LDS_BYTES = 3776 + 64;
+constexpr uint32_t CANON_LDS_TRASH = 3504, CANON_LDS_BYTES = 3504 + 64;
 static_assert(CANON_LDS_BYTES <= PARSE_STAGE_BYTES, "the front end lends its staging buffer to the canonicaliser");
 __device__ __forceinline__ void canon_body_wave(const BatchDev& B, uint32_t i, uint32_t mode, uint32_t flags, uint32_t boff,
                                                 uint32_t blen, uint64_t len_tag, uint8_t* lds) {

@@ -13,7 +13,7 @@
 // Execution model.  Control flow is wave-uniform (one e-mail, one parser state); the 64 lanes
 // are used as a 64-byte-wide scanner: each primitive looks at 64 consecutive bytes at once and
 // turns per-byte predicates into 64-bit ballot masks (find first / find last / stream
-// compaction by popcount prefix).  The head of the e-mail (3.75 KB: the header block of ordinary mail) is staged
+// compaction by popcount prefix).  The head of the e-mail (3.5 KB: the header block of ordinary mail) is staged
 // in LDS with 16-byte lane-contiguous loads; the per-e-mail tables (header spans, tag records, the FWS-stripped
 // tag values) live in LDS too.  In round 0 the kernel also does the batch's bookkeeping (batch_prologue), and
 // after the parse the same wave canonicalises the body (canon.hip.h) — one launch for the whole front end.
@@ -85,7 +85,7 @@ struct BatchDev {
   const EmailMeta* meta_verify; // mode 1 only: the verify pass's meta
 };
 constexpr uint32_t PRE_SLACK = 1024;
-constexpr uint32_t HDR_LDS_ENTRIES = 128;               // header spans kept in LDS; entries 128..255 overflow to the scratch slot
+constexpr uint32_t HDR_LDS_ENTRIES = 64;                // header spans kept in LDS; entries 64..255 overflow to the scratch slot
 constexpr uint32_t HDR_OVF_BYTES = (ZKE_MAX_HEADERS - HDR_LDS_ENTRIES) * 16;
 constexpr uint32_t SCR_PER_EMAIL = HDR_OVF_BYTES + PRE_SLACK + 64;      // fixed part of an e-mail's scratch slot
 constexpr uint32_t CLEAN_PER_EMAIL = 32;
@@ -118,7 +118,7 @@ __device__ __forceinline__ void batch_prologue(const BatchDev& B, uint32_t i, bo
     }
   }
 }
-constexpr uint32_t PARSE_STAGE_BYTES = 3840;   // header blocks beyond this are read from HBM past the staged part
+constexpr uint32_t PARSE_STAGE_BYTES = 3568;   // header blocks beyond this are read from HBM past the staged part
 
 // ------------------------------------------------------------------ byte strings and windows
 struct Str {                  // logical string over global memory with one optional excision
@@ -286,8 +286,8 @@ struct ParseLds {
   __attribute__((aligned(16))) uint8_t stage[PARSE_STAGE_BYTES];   // head of the e-mail (header block), copied in 16-byte lanes
 };
 
-// Header span table: 128 entries in LDS (10 KB of LDS per wave would cap a CU at 16 front-end waves; 8 KB lets the
-// register budget decide), the rest — e-mails with more than 128 header fields — in the e-mail's scratch slot.
+// Header span table: 64 entries in LDS (10 KB of LDS per wave would cap a CU at 16 front-end waves; 6.7 KB lets the
+// register budget decide: 24), the rest — e-mails with more than 64 header fields — in the e-mail's scratch slot.
 // The overflow is written and read back by the same wave: the reads go around L1 (agent-scope atomic loads).
 struct HdrSpan { uint32_t ks, ke, vs, ve; };
 __device__ __forceinline__ void hdr_put(ParseLds& L, uint32_t* ovf, uint32_t x, uint32_t ks, uint32_t ke, uint32_t vs, uint32_t ve) {
@@ -622,7 +622,7 @@ __device__ __forceinline__ void canon_body_wave(const BatchDev& B, uint32_t i, u
 
 __device__ const uint8_t DKIM_NAME[14] = {'D', 'K', 'I', 'M', '-', 'S', 'i', 'g', 'n', 'a', 't', 'u', 'r', 'e'};
 
-__global__ __launch_bounds__(64, 5) void parse_kernel(ParseArgs A) {
+__global__ __launch_bounds__(64, 6) void parse_kernel(ParseArgs A) {
   __shared__ ParseLds L;
   const BatchDev& B = A.b;
   const uint32_t i = blockIdx.x;
