@@ -154,9 +154,11 @@ def main():
     # step at the end".  (Measured alternatives on this box, forced through RCCL at N = 1: an all-gather inside every
     # step costs 14 %; one per 20 steps on a stream of its own, joined to the compute streams by events, 56 %.)
     rec_bytes = n * 192
-    n_slices = max(S, args.steps) if use_dist else S
+    cap_slices = max(S, (4 << 30) // (world * rec_bytes))          # keep the gathered buffer under 4 GiB: beyond that many
+    n_slices = min(max(S, args.steps), cap_slices) if use_dist else S   # steps the slices wrap and the newest records are exchanged
+    g_steps = min(args.steps, n_slices)
     results_all = torch.zeros(n_slices * rec_bytes, dtype=torch.uint8, device=dev)
-    gathered_all = torch.zeros(world * args.steps * rec_bytes, dtype=torch.uint8, device=dev) if use_dist else None
+    gathered_all = torch.zeros(world * g_steps * rec_bytes, dtype=torch.uint8, device=dev) if use_dist else None
     eng = engines[0]
     stream_h = [streams[k].cuda_stream for k in range(S)]
     base_ptr = results_all.data_ptr()
@@ -182,7 +184,7 @@ def main():
         step()
     if use_dist:
         torch.cuda.synchronize()                      # every batch of this rank is done
-        dist.all_gather_into_tensor(gathered_all, results_all[:args.steps * rec_bytes])
+        dist.all_gather_into_tensor(gathered_all, results_all[:g_steps * rec_bytes])
     fence()
     dt = time.perf_counter() - t0
     if use_dist:
@@ -203,9 +205,9 @@ def main():
             assert bytes(rec[j]["body_hash"]) == it["body_hash"] and bytes(rec[j]["header_hash"]) == it["header_hash"]
     if use_dist and not nocheck:
         ok_all = int((gathered_all.view(torch.int32).view(-1, 48)[:, 0] == 0).sum().item())      # status word of every record
-        assert ok_all == world * args.steps * n, (ok_all, world * args.steps * n)
-        mine = gathered_all[rank * args.steps * rec_bytes:(rank + 1) * args.steps * rec_bytes]
-        assert bool((mine == results_all[:args.steps * rec_bytes]).all().item())
+        assert ok_all == world * g_steps * n, (ok_all, world * g_steps * n)
+        mine = gathered_all[rank * g_steps * rec_bytes:(rank + 1) * g_steps * rec_bytes]
+        assert bool((mine == results_all[:g_steps * rec_bytes]).all().item())
 
     # ---- per-kernel device time, HIP events on the launch stream (second pass, same steps)
     # (one batch at a time on engine 0, so a launch's duration is not stretched by its neighbours)
