@@ -280,6 +280,12 @@ def build_limit_cases() -> List[Case]:
     k0 = K()
     many = [(b"X-Filler-%d" % i, b"v%d" % i) for i in range(240)]
     cs.append(mk("pass_250_headers", many + _hdrs(30), _body(200, 30), k0))
+    # the device keeps 64 header spans in LDS and the rest in its scratch slot: both sides of that boundary, with the
+    # signed headers on either side of it
+    for nfill in (53, 54, 55, 63, 64, 65, 127, 128):
+        fill = [(b"X-Filler-%d" % i, b"v%d" % i) for i in range(nfill)]
+        cs.append(mk(f"pass_{nfill}_fillers_before", fill + _hdrs(31), _body(200, 31), k0))
+        cs.append(mk(f"pass_{nfill}_fillers_after", _hdrs(31) + fill, _body(200, 31), k0))
     too_many = [(b"X-Filler-%d" % i, b"v") for i in range(260)]
     cs.append(mk("unsupported_300_headers", too_many + _hdrs(30), _body(200, 30), k0,
                  status=A.ZKE_UNSUPPORTED, detail=A.D_U_TOO_MANY_HEADERS, check_inter=False))
