@@ -237,9 +237,9 @@ constexpr size_t sha256_lds_bytes() { return 4 * (64 * (T + 16) + 64 * 16); }
 // are — so the only way to shorten the chain is to put fewer instructions on it.  The message schedule
 // (W[16..63], ~480 VALU per block) does not depend on the chaining state: wave 0 (feeder) fetches the bytes,
 // builds K[t] + W[t] for block k+1 and leaves the 64 words per lane in LDS while wave 1 (rounds) runs the 64
-// rounds of block k on what the feeder left the step before.  One s_barrier per block; ~900 instead of ~1 400
+// rounds of block k from registers it filled from that buffer.  Two s_barriers per block; ~900 instead of ~1 400
 // instructions on the critical path.  Groups that contain a SHA-1 job fall back to the one-wave routine.
-// LDS per group: slab 64 x (T+16) + descriptors 1 KB + 2 x 64 lanes x 68 words of K+W (row stride 68 words = 4 banks
+// LDS per group: slab 64 x (T+16) + descriptors 1 KB + 64 lanes x 68 words of K+W (row stride 68 words = 4 banks
 // mod 64: conflict-free 16-byte writes and reads, a quarter of the LDS instructions of word accesses).
 constexpr uint32_t SHA_K[64] = {
     0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
@@ -254,7 +254,7 @@ constexpr uint32_t SHA_K[64] = {
 constexpr int SHA_KW_ROW = 68;        // dwords per lane and buffer
 
 template <int T>
-constexpr size_t sha256_pair_lds_bytes() { return 64 * (T + 16) + 64 * 16 + 2 * 64 * SHA_KW_ROW * 4; }
+constexpr size_t sha256_pair_lds_bytes() { return 64 * (T + 16) + 64 * 16 + 64 * SHA_KW_ROW * 4; }
 
 template <int T>
 __global__ __launch_bounds__(128) void sha256_pair_kernel(const ShaJob* __restrict__ jobs, uint32_t n) {
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(128) void sha256_pair_kernel(const ShaJob* __restri
   const int role = threadIdx.x >> 6;               // 0 feeder, 1 rounds
   uint8_t* slab = lds_raw;
   uint8_t* desc = slab + 64 * ROW;
-  uint32_t* kw = (uint32_t*)(desc + 64 * 16);      // [2][64 lanes][SHA_KW_ROW]: a lane's 64 words are contiguous (b128 accesses)
+  uint32_t* kw = (uint32_t*)(desc + 64 * 16);      // [64 lanes][SHA_KW_ROW]: a lane's 64 words are contiguous (b128 accesses)
 
   const uint32_t m = blockIdx.x * 64 + lane;       // both waves look at the same 64 jobs
   uint64_t my_src = 0, my_dst = 0;
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(128) void sha256_pair_kernel(const ShaJob* __restri
         w[4 * q + 0] = __builtin_bswap32(v.x); w[4 * q + 1] = __builtin_bswap32(v.y);
         w[4 * q + 2] = __builtin_bswap32(v.z); w[4 * q + 3] = __builtin_bswap32(v.w);
       }
-      uint4* dst = (uint4*)(kw + (kb & 1) * (64 * SHA_KW_ROW) + lane * SHA_KW_ROW);
+      uint4* dst = (uint4*)(kw + lane * SHA_KW_ROW);
       uint32_t o4[4];
 #pragma unroll
       for (int i = 0; i < 64; i++) {
@@ -412,8 +412,18 @@ __global__ __launch_bounds__(128) void sha256_pair_kernel(const ShaJob* __restri
       sched(0);
     }
     __syncthreads();
-    // Both waves run exactly max_nblk steps (same jobs, same maximum), one barrier per step.
+    // Both waves run exactly max_nblk steps (same jobs, same maximum).  ONE K+W buffer (a group then needs 28 KB of
+    // LDS instead of 45 KB and finds room on a CU that front-end waves of other batches have nearly filled): the
+    // rounds wave pulls the block's 64 words into registers, barrier, then the feeder overwrites the buffer with the
+    // next block's while the rounds run from registers, barrier.
     for (uint32_t kb = 0; kb < max_nblk; kb++) {
+      uint4 kq[16];
+      if (role == 1) {
+        const uint4* src = (const uint4*)(kw + lane * SHA_KW_ROW);
+#pragma unroll
+        for (int q = 0; q < 16; q++) kq[q] = src[q];
+      }
+      __syncthreads();                                // the buffer has been read
       if (role == 0) {
         const uint32_t nb = kb + 1;
         if (nb < max_nblk) {
@@ -424,13 +434,11 @@ __global__ __launch_bounds__(128) void sha256_pair_kernel(const ShaJob* __restri
           sched(nb);
         }
       } else {
-        const uint4* src = (const uint4*)(kw + (kb & 1) * (64 * SHA_KW_ROW) + lane * SHA_KW_ROW);
-        uint4 k4 = make_uint4(0, 0, 0, 0);
         uint32_t a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
 #pragma unroll
         for (int i = 0; i < 64; i++) {
           const uint32_t S1 = xor3(rotr32(e, 6), rotr32(e, 11), rotr32(e, 25));
-          if ((i & 3) == 0) k4 = src[i >> 2];
+          const uint4 k4 = kq[i >> 2];
           const uint32_t kwi = (i & 3) == 0 ? k4.x : (i & 3) == 1 ? k4.y : (i & 3) == 2 ? k4.z : k4.w;
           const uint32_t t1 = (h + S1 + ch3(e, f, g)) + kwi;
           const uint32_t S0 = xor3(rotr32(a, 2), rotr32(a, 13), rotr32(a, 22));
@@ -439,7 +447,7 @@ __global__ __launch_bounds__(128) void sha256_pair_kernel(const ShaJob* __restri
         }
         if (kb < my_nblk) { st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h; }
       }
-      __syncthreads();
+      __syncthreads();                                // the next block's words are in the buffer
     }
     if (role == 0) return;
   }
