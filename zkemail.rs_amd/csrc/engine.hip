@@ -152,10 +152,10 @@ int launch_sha_any(zke_engine* e, const ShaJob* jobs, uint32_t n, hipStream_t s)
 int launch_rsa(zke_engine* e, const RsaJob* jobs, uint32_t n, const uint8_t* hash_base, size_t hash_stride,
                uint32_t* ok, uint8_t* em, hipStream_t s, bool any_big, const uint8_t* key_hash_base, const FinArgs& fin) {
   if (n == 0) return 0;
-  const uint32_t grid = (n + 3) / 4;
+  const uint32_t grid = n;
   KeyCacheEntry* cache = key_hash_base ? e->key_cache.as<KeyCacheEntry>() : nullptr;
   (void)any_big;
-  hipLaunchKernelGGL(rsa_verify_kernel, dim3(grid), dim3(256), 0, s, jobs, n, hash_base, hash_stride, ok, em, cache, key_hash_base, fin);
+  hipLaunchKernelGGL(rsa_verify_kernel, dim3(grid), dim3(64), 0, s, jobs, n, hash_base, hash_stride, ok, em, cache, key_hash_base, fin);
   HIPCHK(e, hipGetLastError());
   return 0;
 }

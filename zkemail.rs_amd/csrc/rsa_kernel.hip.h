@@ -4,7 +4,7 @@
 
 namespace zke {
 
-// One wave per job.  blockDim = 256 (4 waves), grid = ceil(n/4).  When `fin.b.results` is set the wave also
+// One wave per job.  blockDim = 64, grid = n.  When `fin.b.results` is set the wave also
 // writes the e-mail's verdict (the former finalize kernel: one launch and ~20 us of serial loads less per batch).
 // ok_out[i]: 1 = signature verifies (EM == EMSA(hash)), 0 = not.  em_out (optional): EM big-endian, 512 B slots,
 // right-aligned like RsaJob.sig.  hash_base + i*hash_stride -> 32-byte SHA-256 of the header preimage.
@@ -139,12 +139,12 @@ __device__ __forceinline__ void rsa_wave(const RsaJob* __restrict__ jobs, uint32
 
 // One kernel for both containers: a wave picks the one-limb-per-lane (<= 2048 bits) or two-limbs-per-lane path
 // from its job's modulus size (wave-uniform branch).
-__global__ __launch_bounds__(256, 6) void rsa_verify_kernel(const RsaJob* __restrict__ jobs, uint32_t n,
+__global__ __launch_bounds__(64, 6) void rsa_verify_kernel(const RsaJob* __restrict__ jobs, uint32_t n,
                                                          const uint8_t* __restrict__ hash_base, size_t hash_stride,
                                                          uint32_t* __restrict__ ok_out, uint8_t* __restrict__ em_out,
                                                          KeyCacheEntry* cache, const uint8_t* __restrict__ key_hash_base,
                                                          FinArgs fin) {
-  const uint32_t job = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t job = blockIdx.x;      // one wave per workgroup: a single free wave slot is enough to place it
   if (job >= n) return;
   if (fin.b.results && fin.b.meta[job].state == ST_PENDING) return;     // waits for a later signature round
   const uint32_t bits = __builtin_amdgcn_readfirstlane(jobs[job].bits);
