@@ -477,6 +477,103 @@ __device__ __forceinline__ uint32_t split_headers(ParseLds& L, uint32_t* ovf, co
   return nh;
 }
 
+// The same split for a header block that lies inside the staged head (every ordinary e-mail), as one streaming pass:
+// per 64-byte chunk three ballots — ':' bytes, LF bytes, and LFs that end a header (successor not SP / HTAB) — and
+// then only bit scans and a few single-byte reads per header, instead of half a dozen window searches per header
+// (2.6 k of the front end's 10 k scalar instructions per e-mail went into the search bookkeeping of the split).
+// Returns false without side effects that matter when the block runs past the staged bytes: the caller then runs
+// split_headers above.
+__device__ __forceinline__ bool split_headers_staged(ParseLds& L, uint32_t* ovf, const Str& raw, uint32_t& nh_out, uint32_t& perr,
+                                                     uint32_t& hdr_end) {
+  const uint32_t len = raw.len, staged = raw.lds_len;
+  const int lane = lane_id();
+  auto sb = [&](uint32_t pos) -> uint32_t { return __builtin_amdgcn_readfirstlane((uint32_t)L.stage[pos]); };   // pos < staged
+  uint32_t ix = 0, nh = 0;
+  uint32_t colon = NONE, vs = 0, from = 0;          // state of the header that starts at ix
+  perr = 0;
+  // line-start rules of mailparse::parse_headers; 0 go on, 1 end of headers, 2 error (perr set), 3 beyond the staged bytes
+  auto line_start = [&]() -> int {
+    if (ix >= len) return 1;
+    if (ix + 1 >= staged && staged < len) return 3;
+    const uint32_t c0 = sb(ix);
+    if (c0 == '\n') return 1;
+    if (c0 == '\r') {
+      if (ix + 1 < len && sb(ix + 1) == '\n') return 1;
+      perr = ZKE_D_HDR_LONE_CR;
+      return 2;
+    }
+    if (c0 == ' ') { perr = ZKE_D_HDR_LEADING_SPACE; return 2; }
+    return 0;
+  };
+  auto put = [&](uint32_t ke, uint32_t a, uint32_t b) -> bool {
+    if (nh >= ZKE_MAX_HEADERS) { perr = ZKE_D_U_TOO_MANY_HEADERS; return false; }
+    hdr_put(L, ovf, nh, ix, ke, a, b);
+    nh++;
+    return true;
+  };
+  // value end: strip trailing CR / LF of [vs, lim)
+  auto value_end = [&](uint32_t lim) -> uint32_t {
+    uint32_t e = lim;
+    while (e > vs) { const uint32_t c = sb(e - 1); if (c != '\r' && c != '\n') break; e--; }
+    return e;
+  };
+  int st = line_start();
+  if (st == 3) return false;
+  if (st == 2) { nh_out = NONE; return true; }
+  bool done = st == 1;
+  for (uint32_t base = 0; !done && base < len; base += 64) {
+    if (staged < len && base + 64 >= staged) return false;              // the chunk and the byte after it must be staged
+    const uint32_t l = base + lane;
+    const uint32_t c = l < len ? (uint32_t)L.stage[l] : OOB;
+    const uint32_t n = l + 1 < len ? (uint32_t)L.stage[l + 1] : OOB;
+    const uint64_t Cm = __ballot(c == ':'), Lm = __ballot(c == '\n');
+    const uint64_t Tm = __ballot(c == '\n' && n != ' ' && n != '\t');
+    for (;;) {
+      if (colon == NONE) {
+        const uint64_t m = (Cm | Lm) & bits_from(ix > base ? ix - base : 0);
+        if (!m) break;                                                    // the key runs on into the next chunk
+        const uint32_t p = base + (uint32_t)__builtin_ctzll(m);
+        if ((Lm >> (p - base)) & 1) {                                     // a line without ':' ends at its LF
+          if (!put(p, p, p)) { nh_out = NONE; return true; }
+          ix = p + 1;
+          st = line_start();
+          if (st == 3) return false;
+          if (st == 2) { nh_out = NONE; return true; }
+          if (st == 1) { done = true; break; }
+          continue;
+        }
+        colon = p;
+        vs = p + 1;
+        while (vs < len) {
+          if (vs >= staged) return false;
+          if (sb(vs) != ' ') break;
+          vs++;
+        }
+        from = p + 1;
+      }
+      const uint64_t m = Tm & bits_from(from > base ? from - base : 0);
+      if (!m) break;                                                      // the value runs on into the next chunk
+      const uint32_t q = base + (uint32_t)__builtin_ctzll(m);
+      if (!put(colon, vs, value_end(q > vs ? q : vs))) { nh_out = NONE; return true; }
+      ix = q + 1; colon = NONE;
+      st = line_start();
+      if (st == 3) return false;
+      if (st == 2) { nh_out = NONE; return true; }
+      if (st == 1) { done = true; break; }
+    }
+  }
+  if (!done && ix < len) {                      // the input ends inside a header: no LF closes it
+    if (colon == NONE) { if (!put(len, len, len)) { nh_out = NONE; return true; } }
+    else if (!put(colon, vs, value_end(len > vs ? len : vs))) { nh_out = NONE; return true; }
+    ix = len;
+  }
+  hdr_end = ix;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  nh_out = nh;
+  return true;
+}
+
 // cfdkim get_body: everything after the first CRLFCRLF (empty when there is none).
 // `from`: a position no CRLFCRLF starts in front of.  After split_headers that is hdr_end - 2: bytes p..p+3 =
 // CRLFCRLF make p+2 a line start that begins with CRLF (the LF at p+1 cannot continue a folded line: CR follows),
@@ -700,7 +797,8 @@ __global__ __launch_bounds__(64, 6) void parse_kernel(ParseArgs A) {
   uint32_t perr;
   uint32_t hdr_end = 0;
   uint32_t* hdr_ovf = (uint32_t*)(regA - HDR_OVF_BYTES);       // in front of region A
-  const uint32_t nh = split_headers(L, hdr_ovf, raw, perr, hdr_end);
+  uint32_t nh = 0;
+  if (!split_headers_staged(L, hdr_ovf, raw, nh, perr, hdr_end)) nh = split_headers(L, hdr_ovf, raw, perr, hdr_end);
   if (nh == NONE) {
     finish(perr == ZKE_D_U_TOO_MANY_HEADERS ? ZKE_UNSUPPORTED : ZKE_PARSE_FAIL, perr);
     return;
