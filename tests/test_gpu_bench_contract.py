@@ -1,0 +1,36 @@
+"""GPU (-m gpu): bench.py's output contract — ONE JSON line with the driver's fields, the `roofline` object of the
+dominant kernel and the `cpu_baseline` object (the oracle timed on this box's cores)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_json_contract():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "60", "--warmup", "10",
+                        "--cpu-seconds", "1", "--no-saturated"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 60 and j["warmup"] == 10 and j["higher_is_better"] is True
+    assert j["scaling"] == "weak" and j["vs_baseline"] is None and j["data"] == "synthetic" and j["unit"] == "emails/s"
+    assert "workload" in j["config"] and "model" not in j["config"]
+    assert j["value"] > 1e5 and abs(j["ms_per_step"] * 1e-3 * j["value"] - 1024) < 1.0        # value = 1024 e-mails per step / time per step
+    rf = j["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
+    cb = j["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb, k
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
