@@ -11,6 +11,7 @@
 // with the trailing empty lines cut off.
 #pragma once
 #include "parse.hip.h"
+#include <type_traits>
 
 namespace zke {
 
@@ -91,51 +92,78 @@ __device__ __forceinline__ void canon_body_wave(const BatchDev& B, uint32_t i, u
     uint32_t last_in = OOB;                   // last byte of the body
     bool tail_done = false;
     for (uint32_t base0 = 0; base0 < blen; base0 += 256u * RING) {
-      // Whole group clean?  The 2 KB in the ring (8 windows, a dword per lane each) are tested with byte-parallel
-      // arithmetic — no TAB, no SP in front of SP / TAB / CR, no WSP at either edge — and then leave as eight
-      // coalesced dword stores: no LDS, no per-window scalar bookkeeping (ordinary text is almost all such
-      // groups).  The last group of the body always takes the window path below, which settles the body's end.
-      if (base0 + 256u * RING < blen && !is_wsp(prev_last)) {
-        auto eqb = [](uint32_t x, uint32_t c) -> uint32_t {       // 0x80 in every byte of x that equals c (exact)
-          const uint32_t y = x ^ (c * 0x01010101u);
-          return ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu);
-        };
-        uint32_t bad = 0;
+      // Clean prefix?  The leading windows of the group that lie wholly in front of the body's last 65 bytes (all
+      // eight, except in the body's last group) are tested with byte-parallel arithmetic, a dword per lane: no byte
+      // that could be WSP (<= 0x20 with bits 1 and 2 clear: SP, TAB and seven control codes, never CR or LF) unless
+      // it is SP-like (bit 5) and the byte behind it is > 0x20; no WSP at either edge.  The test errs only towards
+      // "not clean".  Such windows leave relaxed canonicalisation as they came (a single SP between words stays one
+      // SP) and go out as coalesced dword stores: no LDS, no per-window scalar bookkeeping — ordinary text is almost
+      // all such windows.  The windows behind the prefix take the path below, which also settles the body's end.
+      const uint32_t rem = blen - base0;
+      uint32_t kstart = 0;                      // first window of this group that takes the window path
+      // FULL: all eight windows (straight-line code, the ring is refilled); otherwise windows [0, nfull), selected
+      // with scalar masks instead of branches.  true: the windows are stored and o / prev_last have moved on.
+      auto clean_prefix = [&](auto full_tag, uint32_t nfull) -> bool {
+        constexpr bool FULL = decltype(full_tag)::value;
+        uint32_t hi[RING];                      // bit 7 of byte j: byte j of q[k] is > 0x20
+#pragma unroll
+        for (int k = 0; k < RING; k++) hi[k] = ((q[k] & 0x7F7F7F7Fu) + 0x5F5F5F5Fu) | q[k];
+        uint32_t bad = 0, glast = 0;
 #pragma unroll
         for (int k = 0; k < RING; k++) {
           const uint32_t x = q[k];
-          uint32_t up = lane_up(x);                                 // the dword after mine (lane + 1)
-          const uint32_t nfirst = k + 1 < RING ? __builtin_amdgcn_readfirstlane(q[(k + 1) & (RING - 1)]) : 0x41414141u;
-          if (lane == 63) up = nfirst;                              // next window (the group's last byte is tested apart)
-          const uint32_t nx = (x >> 8) | (up << 24);                // byte i+1 under byte i
-          bad |= (eqb(x, 0x20) & (eqb(nx, 0x20) | eqb(nx, 0x09) | eqb(nx, 0x0d))) | eqb(x, 0x09);
-        }
-        const uint32_t glast = __builtin_amdgcn_readlane(q[RING - 1], 63) >> 24;
-        if (!is_wsp(glast) && __ballot(bad != 0) == 0) {
-          if (fill) {                                               // bytes of an earlier, dirty group still in LDS
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            for (uint32_t bq = 16u * lane; bq + 16 <= fill; bq += 1024) *(uint4_store_unaligned*)(regB + o + bq) = *(const uint4*)(lds + bq);
-            const uint32_t tb = (fill & ~15u) + lane;
-            if (lane < 16 && tb < fill) regB[o + tb] = lds[tb];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            o += fill; fill = 0;
+          // the dword after mine: lane + 1, lane 63 takes the next window's first (behind the group's last byte
+          // nothing is known: that byte is tested apart)
+          const uint32_t nfirst = k + 1 < RING ? __builtin_amdgcn_readfirstlane(hi[(k + 1) & (RING - 1)]) : 0xFFFFFFFFu;
+          const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp((int)nfirst, (int)hi[k], 0x130 /*wave_shl:1*/, 0xf, 0xf, false);
+          const uint32_t nh = __builtin_amdgcn_alignbit(up, hi[k], 8);                            // byte j+1 under byte j
+          const uint32_t wl = __builtin_amdgcn_bitop3_b32(hi[k], x << 6, x << 5, 0x01);          // ~(a | b | c): WSP-like
+          const uint32_t v = __builtin_amdgcn_bitop3_b32(wl, nh, x << 2, 0x70);                  // a & ~(b & c)
+          if (FULL) bad |= v;
+          else {
+            const uint32_t mk = (uint32_t)k < nfull ? 0xFFFFFFFFu : 0u;                           // scalar
+            bad = __builtin_amdgcn_bitop3_b32(bad, v, mk, 0xF8);                                  // a | (b & c)
+            const uint32_t g = __builtin_amdgcn_readlane(x, 63) >> 24;
+            glast = (uint32_t)k + 1 == nfull ? g : glast;
           }
+        }
+        if (FULL) glast = __builtin_amdgcn_readlane(q[RING - 1], 63) >> 24;
+        if (is_wsp(glast) || __ballot((bad & 0x80808080u) != 0) != 0) return false;
+        if (fill) {                                                 // bytes of an earlier, dirty group still in LDS
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          for (uint32_t bq = 16u * lane; bq + 16 <= fill; bq += 1024) *(uint4_store_unaligned*)(regB + o + bq) = *(const uint4*)(lds + bq);
+          const uint32_t tb = (fill & ~15u) + lane;
+          if (lane < 16 && tb < fill) regB[o + tb] = lds[tb];
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          o += fill; fill = 0;
+        }
 #pragma unroll
-          for (int k = 0; k < RING; k++) {
+        for (int k = 0; k < RING; k++) {
+          if (FULL) {
             *(u32_unaligned*)(regB + o + 256u * k + 4 * lane) = q[k];
             q[k] = load4(base0 + 256u * RING + 256u * k + 4 * lane);
+          } else if ((uint32_t)k < nfull) {
+            *(u32_unaligned*)(regB + o + 256u * k + 4 * lane) = q[k];
           }
-          o += 256u * RING;
-          prev_last = glast;
-          continue;
+        }
+        o += 256u * nfull;
+        prev_last = glast;
+        return true;
+      };
+      if (!is_wsp(prev_last)) {
+        if (rem > 256u * RING) {
+          if (clean_prefix(std::true_type{}, (uint32_t)RING)) continue;
+        } else if (rem >= 321u) {               // the body's last group: at least 65 bytes stay for the window path
+          const uint32_t nf = (rem - 65u) >> 8;
+          if (clean_prefix(std::false_type{}, nf)) kstart = nf;
         }
       }
 #pragma unroll
       for (int k = 0; k < RING; k++) {
         const uint32_t base = base0 + 256u * k;
-        if (base < blen) {                    // wave-uniform
+        if ((uint32_t)k >= kstart && base < blen) {   // wave-uniform
           const uint32_t cur = q[k];
           q[k] = load4(base + 256u * RING + 4 * lane);                             // RING steps ahead
           const uint32_t nxtw = q[(k + 1) & (RING - 1)];                                    // the window after this one

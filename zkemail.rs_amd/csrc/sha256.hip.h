@@ -98,6 +98,14 @@ __device__ __forceinline__ void sha1_compress(uint32_t (&st)[8], uint32_t (&w)[1
 }
 
 typedef uint4 __attribute__((aligned(1))) uint4_unaligned;
+// Message bytes are in HBM, but their addresses arrive as integers (ShaJob::src), so the compiler would emit FLAT
+// loads: those count on lgkmcnt as well as vmcnt, and every wait for an LDS read behind one (the next row's
+// descriptor) then waits for HBM too — a tile's loads went out one at a time.  Typed as address space 1 they are
+// global_load_*: all of a tile's loads are in flight together and only commit() waits for them.
+typedef uint32_t u32x4_raw __attribute__((ext_vector_type(4)));          // a plain vector: the host pass cannot bind HIP's uint4 class across address spaces
+typedef const u32x4_raw __attribute__((aligned(1), address_space(1)))* gptr_u4;
+typedef const uint8_t __attribute__((address_space(1)))* gptr_u8;
+typedef uint32_t __attribute__((address_space(1)))* gptr_out32;
 
 // Launch: blockDim = 256 (4 independent waves), grid = ceil(n / 256).
 // LDS: 4 waves * 64 rows * (T + 16) bytes  (T = 256 -> 69,632 B per block).
@@ -149,21 +157,23 @@ __global__ __launch_bounds__(256) void sha256_batch_kernel(const ShaJob* __restr
   auto fetch = [&](uint32_t blk0) {
     const uint32_t tile_off = blk0 * 64;
     live = 0;
+    uint4 dsc[LPR];                              // every row descriptor first (one ds_read_b128 each), then the loads
+#pragma unroll
+    for (int g = 0; g < LPR; g++) dsc[g] = *(const uint4*)(desc + (g * RPI + lane / LPR) * 16);
 #pragma unroll
     for (int g = 0; g < LPR; g++) {
-      const int row = g * RPI + lane / LPR;
       const int chunk = lane % LPR;
-      const uint64_t rsrc = *(const uint64_t*)(desc + row * 16);
-      const uint32_t rlen = *(const uint32_t*)(desc + row * 16 + 8);
-      const uint32_t rnblk = *(const uint32_t*)(desc + row * 16 + 12);
+      const uint64_t rsrc = ((uint64_t)dsc[g].y << 32) | dsc[g].x;
+      const uint32_t rlen = dsc[g].z;
+      const uint32_t rnblk = dsc[g].w;
       const uint32_t off = tile_off + chunk * 16;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (blk0 < rnblk) {                      // rows that are already finished are skipped
         live |= 1u << g;
         if (off + 16 <= rlen) {
-          v = *(const uint4_unaligned*)(rsrc + off);
+          { const u32x4_raw t4 = *(gptr_u4)(rsrc + off); v = make_uint4(t4.x, t4.y, t4.z, t4.w); }
         } else if (off < rlen) {               // last partial chunk of the message: byte loads, never past the end
-          const uint8_t* p = (const uint8_t*)(rsrc + off);
+          gptr_u8 p = (gptr_u8)(rsrc + off);
           uint32_t rem = rlen - off, t[4] = {0, 0, 0, 0};
           for (uint32_t b = 0; b < rem; b++) t[b >> 2] |= (uint32_t)p[b] << (8 * (b & 3));
           v = make_uint4(t[0], t[1], t[2], t[3]);
@@ -221,7 +231,7 @@ __global__ __launch_bounds__(256) void sha256_batch_kernel(const ShaJob* __restr
     if (more) commit(next);
   }
   if (m < n && my_dst) {
-    uint32_t* out = (uint32_t*)my_dst;      // digests are 4-byte aligned (result records / engine buffers)
+    gptr_out32 out = (gptr_out32)my_dst;      // digests are 4-byte aligned (result records / engine buffers)
 #pragma unroll
     for (int i = 0; i < 8; i++) out[i] = (my_algo && i >= 5) ? 0u : __builtin_bswap32(st[i]);
   }
@@ -300,21 +310,23 @@ __global__ __launch_bounds__(128) void sha256_pair_kernel(const ShaJob* __restri
   auto fetch = [&](uint32_t blk0) {
     const uint32_t tile_off = blk0 * 64;
     live = 0;
+    uint4 dsc[LPR];                              // every row descriptor first (one ds_read_b128 each), then the loads
+#pragma unroll
+    for (int g = 0; g < LPR; g++) dsc[g] = *(const uint4*)(desc + (g * RPI + lane / LPR) * 16);
 #pragma unroll
     for (int g = 0; g < LPR; g++) {
-      const int row = g * RPI + lane / LPR;
       const int chunk = lane % LPR;
-      const uint64_t rsrc = *(const uint64_t*)(desc + row * 16);
-      const uint32_t rlen = *(const uint32_t*)(desc + row * 16 + 8);
-      const uint32_t rnblk = *(const uint32_t*)(desc + row * 16 + 12);
+      const uint64_t rsrc = ((uint64_t)dsc[g].y << 32) | dsc[g].x;
+      const uint32_t rlen = dsc[g].z;
+      const uint32_t rnblk = dsc[g].w;
       const uint32_t off = tile_off + chunk * 16;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (blk0 < rnblk) {
         live |= 1u << g;
         if (off + 16 <= rlen) {
-          v = *(const uint4_unaligned*)(rsrc + off);
+          { const u32x4_raw t4 = *(gptr_u4)(rsrc + off); v = make_uint4(t4.x, t4.y, t4.z, t4.w); }
         } else if (off < rlen) {
-          const uint8_t* p = (const uint8_t*)(rsrc + off);
+          gptr_u8 p = (gptr_u8)(rsrc + off);
           uint32_t rem = rlen - off, t[4] = {0, 0, 0, 0};
           for (uint32_t b = 0; b < rem; b++) t[b >> 2] |= (uint32_t)p[b] << (8 * (b & 3));
           v = make_uint4(t[0], t[1], t[2], t[3]);
@@ -452,7 +464,7 @@ __global__ __launch_bounds__(128) void sha256_pair_kernel(const ShaJob* __restri
     if (role == 0) return;
   }
   if (m < n && my_dst) {
-    uint32_t* out = (uint32_t*)my_dst;
+    gptr_out32 out = (gptr_out32)my_dst;
 #pragma unroll
     for (int i = 0; i < 8; i++) out[i] = (my_algo && i >= 5) ? 0u : __builtin_bswap32(st[i]);
   }
