@@ -315,3 +315,69 @@ def multi_signature_case(n_bad: int) -> Case:
         raw_bad, _ = sign_email(hs, _body(120 + j, 41 + j), k0, SignSpec(selector=f"old{j}"))
         prefix += raw_bad[:raw_bad.find(b"Received:")]
     return Case(f"pass_after_{n_bad}_failed_signatures", Email("example.com", prefix + raw, PublicKey(k0.pkcs1_der)), A.ZKE_OK, None, inter)
+
+
+def prefix_edge_bodies():
+    """Bodies around the thresholds of the relaxed body canonicaliser's clean-prefix path (2 KB groups of eight
+    256-byte windows; the last 65..320 bytes of a body always take the window path): every length class, with one
+    change at a window or group edge — WSP runs, TAB, SP in front of CRLF, control codes the byte-parallel test
+    takes for possible WSP (0x00, 0x01, 0x08, 0x10, 0x19), bytes >= 0x80 — and the ways a body can end."""
+    rng = np.random.default_rng(4242)
+    lens = [320, 321, 322, 400, 576, 577, 578, 833, 2048, 2112, 2113, 2114, 2368, 2369, 2370, 4096, 4097, 4159, 4160,
+            4161, 4162, 4416, 4417, 6000, 8192 + 321, 12288 + 66]
+    out = []
+    for L in lens:
+        base = bytearray(synth.ascii_body(rng, L))
+        out.append((f"clean_{L}", bytes(base)))
+        edges = sorted({p for p in (0, 1, 254, 255, 256, 257, 511, 512, 2046, 2047, 2048, 2049, 2303, 2304, 4095, 4096,
+                                    L - 322, L - 321, L - 320, L - 67, L - 66, L - 65, L - 64, L - 63, L - 5) if 0 <= p < L - 4})
+        for p in edges:
+            q = p
+            while q + 3 < L and any(c in (13, 10) for c in base[q:q + 3]):
+                q += 1                                    # leave the CRLF pairs alone (the Python signer splits on them)
+            if q + 3 >= L:
+                continue
+            kind = ["sp2", "tab", "spcr", "ctl", "hi", "sptab"][int(rng.integers(0, 6))]
+            b = bytearray(base)
+            if kind == "sp2":
+                b[q:q + 2] = b"  "
+            elif kind == "tab":
+                b[q] = 9
+            elif kind == "sptab":
+                b[q:q + 2] = b" \t"
+            elif kind == "ctl":
+                b[q] = [0, 1, 8, 0x10, 0x19, 0x11][int(rng.integers(0, 6))]
+            elif kind == "hi":
+                b[q] = 0xC3
+            else:
+                e = bytes(b).find(b"\r\n", q)
+                if e <= 0:
+                    continue
+                b[e - 1] = 0x20
+            out.append((f"{kind}_{L}_{p}", bytes(b)))
+        core = bytes(base)
+        out.append((f"no_final_crlf_{L}", core[:-2]))
+        out.append((f"ends_sp_{L}", core[:-2] + b" "))
+        out.append((f"ends_sp_crlf_{L}", core[:-2] + b" \r\n"))
+        for blanks in (1, 2, 31, 33, 40, 170):
+            out.append((f"blank_lines_{blanks}_{L}", core + b"\r\n" * blanks))
+    return out
+
+
+_PREFIX_EDGE_CACHE = None
+
+
+def prefix_edge_emails():
+    """(names, emails, intermediates): the bodies above, signed relaxed/relaxed by the Python signer."""
+    global _PREFIX_EDGE_CACHE
+    if _PREFIX_EDGE_CACHE is None:
+        named = prefix_edge_bodies()
+        keys = synth.keys_of(2048, 2)
+        rng = np.random.default_rng(7)
+        emails, inter = [], []
+        for i, (_, body) in enumerate(named):
+            raw, it = sign_email(synth.std_headers(rng, i, "example.com"), body, keys[i % 2], SignSpec())
+            emails.append(Email("example.com", raw, PublicKey(keys[i % 2].pkcs1_der)))
+            inter.append(it)
+        _PREFIX_EDGE_CACHE = ([n for n, _ in named], emails, inter)
+    return _PREFIX_EDGE_CACHE

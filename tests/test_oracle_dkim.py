@@ -133,3 +133,19 @@ LIMITS = cases.build_limit_cases() + [cases.multi_signature_case(k) for k in (2,
 @pytest.mark.parametrize("case", LIMITS, ids=[c.name for c in LIMITS])
 def test_oracle_limit_case(oracle, case):
     test_oracle_case(oracle, case)
+
+
+def test_body_shapes_around_window_edges(oracle):
+    """Relaxed bodies with WSP runs, TABs, control codes and every kind of ending at 256-byte / 2 KB offsets
+    (the device canonicaliser's window and group edges), signed by the independent Python signer: the oracle's
+    canonical body must be the signer's, byte for byte."""
+    names, emails, inter = cases.prefix_edge_emails()
+    mx = max(len(e.raw_email) for e in emails)
+    dbg = A.DebugBuffers(len(emails), 2 * mx + 4096, mx + 64)
+    r = oracle.verify_batch(A.PackedBatch(emails), dbg, threads=4)
+    for i, it in enumerate(inter):
+        if names[i].startswith("ends_sp_") and not names[i].startswith("ends_sp_crlf"):
+            continue      # cfdkim keeps the SP of an unterminated last line (DESIGN §4); the signer follows the RFC
+        assert int(r[i]["status"]) == A.ZKE_OK, (names[i], int(r[i]["status"]), int(r[i]["detail"]))
+        bl = int(dbg.full_len[i])
+        assert bl == len(it["canon_body"]) and bytes(dbg.canon_body[i, :bl]) == it["canon_body"], names[i]
