@@ -9,7 +9,8 @@ A step = one pass of the hot path (verify_email: parse -> canonicalise -> SHA-25
 verdict) over one batch of BASELINE.json configs[1]: 1 024 synthetic DKIM-signed e-mails, 4 KB
 canonical body, RSA-2048, DKIM only.  Inputs are resident in HBM before the timed region; every
 rank verifies its own batch (independent e-mails: weak scaling, no data-path collective) and the
-fixed-size result records of every step are all-gathered over RCCL at the end of the timed region when N > 1.
+per-e-mail witnesses (status + the two output hashes, 72 B) of every step are all-gathered over RCCL at the end of the
+timed region when N > 1.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` (the SHA-256
 batch kernel, HIP-event timed on the launch stream) and `cpu_baseline` (the CPU oracle — a port,
@@ -103,6 +104,7 @@ def main():
     import zkemail_rs_amd as z
     from zkemail_rs_amd import _abi as A
     from zkemail_rs_amd import synth
+    from zkemail_rs_amd import distributed as D
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
@@ -154,11 +156,13 @@ def main():
     # step at the end".  (Measured alternatives on this box, forced through RCCL at N = 1: an all-gather inside every
     # step costs 14 %; one per 20 steps on a stream of its own, joined to the compute streams by events, 56 %.)
     rec_bytes = n * 192
-    cap_slices = max(S, (4 << 30) // (world * rec_bytes))          # keep the gathered buffer under 4 GiB: beyond that many
+    wit_bytes = n * 72                # what the ranks exchange per step: the witness of every e-mail (status, detail, the two
+                                      # output hashes); the other 120 bytes of a record are intermediates and stay in the rank's HBM
+    cap_slices = max(S, (4 << 30) // (world * wit_bytes))          # keep the gathered buffer under 4 GiB: beyond that many
     n_slices = min(max(S, args.steps), cap_slices) if use_dist else S   # steps the slices wrap and the newest records are exchanged
     g_steps = min(args.steps, n_slices)
     results_all = torch.zeros(n_slices * rec_bytes, dtype=torch.uint8, device=dev)
-    gathered_all = torch.zeros(world * g_steps * rec_bytes, dtype=torch.uint8, device=dev) if use_dist else None
+    gathered_all = torch.zeros(world * g_steps * wit_bytes, dtype=torch.uint8, device=dev) if use_dist else None
     eng = engines[0]
     stream_h = [streams[k].cuda_stream for k in range(S)]
     base_ptr = results_all.data_ptr()
@@ -184,7 +188,7 @@ def main():
         step()
     if use_dist:
         torch.cuda.synchronize()                      # every batch of this rank is done
-        dist.all_gather_into_tensor(gathered_all, results_all[:g_steps * rec_bytes])
+        dist.all_gather_into_tensor(gathered_all, D.witness_tensor(results_all[:g_steps * rec_bytes]))
     fence()
     dt = time.perf_counter() - t0
     if use_dist:
@@ -204,10 +208,10 @@ def main():
             it = wl.inter[j]
             assert bytes(rec[j]["body_hash"]) == it["body_hash"] and bytes(rec[j]["header_hash"]) == it["header_hash"]
     if use_dist and not nocheck:
-        ok_all = int((gathered_all.view(torch.int32).view(-1, 48)[:, 0] == 0).sum().item())      # status word of every record
+        ok_all = int((gathered_all.view(torch.int32).view(-1, 18)[:, 0] == 0).sum().item())      # status word of every witness
         assert ok_all == world * g_steps * n, (ok_all, world * g_steps * n)
-        mine = gathered_all[rank * g_steps * rec_bytes:(rank + 1) * g_steps * rec_bytes]
-        assert bool((mine == results_all[:g_steps * rec_bytes]).all().item())
+        mine = gathered_all[rank * g_steps * wit_bytes:(rank + 1) * g_steps * wit_bytes]
+        assert bool((mine == D.witness_tensor(results_all[:g_steps * rec_bytes])).all().item())
 
     # ---- per-kernel device time, HIP events on the launch stream (second pass, same steps)
     # (one batch at a time on engine 0, so a launch's duration is not stretched by its neighbours)
@@ -281,7 +285,7 @@ def main():
         "config": {"workload": f"BASELINE configs[1]: batch {n} e-mails, 4 KB body, RSA-2048, DKIM-only verify_email"
                    if args.workload == "c2" else f"{args.workload}: {cfg}",
                    "emails_per_step_per_gpu": n, "body_bytes": cfg["body_len"], "rsa_bits": cfg.get("rsa_bits", 0), "algo": cfg.get("algo", "rsa-sha256"),
-                   "inputs": "HBM-resident raw e-mails", "batches_in_flight": S, "collective": "one RCCL all_gather of every step's 192-B result records at the end of the timed region" if use_dist else "none"},
+                   "inputs": "HBM-resident raw e-mails", "batches_in_flight": S, "collective": "one RCCL all_gather of every step's 72-B witnesses (status + output hashes of each e-mail) at the end of the timed region" if use_dist else "none"},
         "roofline": roof,
         "kernels_us": {k: round(v, 2) for k, v in kern.items()},
         "sha256_saturated": sha_sat,

@@ -29,6 +29,9 @@ local = orc.verify_batch(A.PackedBatch(wl.emails[lo:hi])) if hi > lo else np.zer
 allrec = D.gather_records(local, [bounds[r + 1] - bounds[r] for r in range(world)])
 full = orc.verify_batch(A.PackedBatch(wl.emails))
 assert allrec.tobytes() == full.tobytes(), "gathered records differ from the single-process batch"
+wit = D.gather_witnesses(local, [bounds[r + 1] - bounds[r] for r in range(world)])
+assert wit.tobytes() == D.witness_of(full).tobytes(), "gathered witnesses differ from the single-process batch"
+assert (wit["status"] == full["status"]).all() and (wit["public_key_hash"] == full["public_key_hash"]).all()
 my_bytes = sum(sizes[lo:hi])
 tot = torch.tensor([my_bytes], dtype=torch.int64)
 dist.all_reduce(tot)

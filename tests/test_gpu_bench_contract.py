@@ -34,3 +34,15 @@ def test_bench_json_contract():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+
+
+def test_bench_exchange_path_through_rccl_on_one_gpu():
+    """The N > 1 code of bench.py — process group over RCCL, the end-of-job all_gather of every step's witnesses, the
+    barrier and the max-over-ranks all_reduce, the check of the gathered witnesses — run with one rank."""
+    env = dict(os.environ, ZKE_BENCH_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "120", "--warmup", "10",
+                        "--no-cpu", "--no-saturated"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert j["n_gpus"] == 1 and "all_gather" in j["config"]["collective"] and j["value"] > 1e5

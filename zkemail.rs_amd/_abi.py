@@ -103,6 +103,11 @@ RESULT_DTYPE = np.dtype([
 ])
 assert RESULT_DTYPE.itemsize == 192
 
+# What verify_email returns per e-mail (EmailVerifierOutput, core/src/structs.rs:64-69, plus the panic site): the part of
+# a zke_result the ranks of a multi-GPU job exchange.  Bytes [0, 8) and [32, 96) of the record.
+WITNESS_DTYPE = np.dtype([("status", "<u4"), ("detail", "<u4"), ("from_domain_hash", "u1", 32), ("public_key_hash", "u1", 32)])
+assert WITNESS_DTYPE.itemsize == 72
+
 
 class zke_batch(C.Structure):
     _fields_ = [
