@@ -243,7 +243,7 @@ def main():
         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(sha_bytes / sha_s / 1e9 / HBM_PEAK_GBS, 5) if sha_s > 0 else None,
         "traffic": traffic, "bytes_per_launch": sha_bytes, "launch_us": round(kern["sha_us"], 2),
         "note": "SHA-256 on CDNA4 is integer-VALU bound: the compression alone sustains 1.82 TB/s on this chip "
-                "(profiles/r01_ubench_sha_alu.txt; v_alignbit/v_add3 issue at half rate), and a 1024-message launch is "
+                "(profiles/r01_ubench_sha_alu.txt: ~1400 VALU per 64-byte block at ~3.9 cycles each), and a 1024-message launch is "
                 "bounded by the 65-block dependency chain of one message (split over two waves: schedule / rounds); see DESIGN.md §3",
     }
 
