@@ -212,6 +212,33 @@ def test_lane_front_end_variant_parity(tmp_path):
     assert r.returncode == 0 and "lane front end ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_rsa_quad_kernel_variant_parity():
+    """The four-lanes-per-signature RSA kernel (csrc/rsa_quad.hip.h) is chosen for batches of >= 2 048 e-mails; forced on
+    (ZKE_RSA_QUAD=1) it must give the oracle's records and EM blocks on the corpus (all key sizes, exponents, bad
+    signatures), the fuzz set, ragged / invalid / rsa-sha1 / mixed-key workloads and several signature rounds."""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent(f"""
+        import sys
+        sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r})
+        import oracle_lib, cases, test_gpu_verify as t
+        import zkemail_rs_amd as z
+        eng, orc = z.Engine(), oracle_lib.load()
+        t.test_case_corpus_parity(eng, orc)
+        for seed in (99, 7, 12):
+            t.test_mutation_fuzz_parity(eng, orc, seed)
+        t.test_workload_parity(eng, orc, dict(n=70, body_len=20000, rsa_bits=2048, seed=7, ragged=True, invalid_frac=0.2))
+        t.test_workload_parity(eng, orc, dict(n=150, body_len=9000, rsa_bits=2048, seed=12, ragged=True, invalid_frac=0.15, algo="rsa-sha1"))
+        t.test_workload_parity(eng, orc, dict(n=257, body_len=1000, rsa_bits=2048, n_keys=16, seed=31, invalid_frac=0.3))
+        t.test_mixed_key_types_one_batch(eng, orc)
+        t.test_signature_rounds(eng, orc)
+        t.test_limits_and_large_header_blocks_parity(eng, orc)
+        print("rsa quad ok")
+    """)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ZKE_RSA_QUAD="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rsa quad ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_limits_and_large_header_blocks_parity(engine, oracle):
     cs = cases.build_limit_cases()
     got, exp, d1, d2 = run_both(engine, oracle, [c.email for c in cs])
