@@ -213,7 +213,7 @@ def test_lane_front_end_variant_parity(tmp_path):
 
 
 def test_rsa_quad_kernel_variant_parity():
-    """The four-lanes-per-signature RSA kernel (csrc/rsa_quad.hip.h) is chosen for batches of >= 2 048 e-mails; forced on
+    """The four- / eight-lanes-per-signature RSA kernel (csrc/rsa_quad.hip.h) is chosen for batches of >= 2 048 e-mails; forced on
     (ZKE_RSA_QUAD=1) it must give the oracle's records and EM blocks on the corpus (all key sizes, exponents, bad
     signatures), the fuzz set, ragged / invalid / rsa-sha1 / mixed-key workloads and several signature rounds."""
     import os, subprocess, sys, textwrap
@@ -230,6 +230,7 @@ def test_rsa_quad_kernel_variant_parity():
         t.test_workload_parity(eng, orc, dict(n=70, body_len=20000, rsa_bits=2048, seed=7, ragged=True, invalid_frac=0.2))
         t.test_workload_parity(eng, orc, dict(n=150, body_len=9000, rsa_bits=2048, seed=12, ragged=True, invalid_frac=0.15, algo="rsa-sha1"))
         t.test_workload_parity(eng, orc, dict(n=257, body_len=1000, rsa_bits=2048, n_keys=16, seed=31, invalid_frac=0.3))
+        t.test_workload_parity(eng, orc, dict(n=90, body_len=2000, rsa_bits=4096, n_keys=8, seed=5, invalid_frac=0.25))      # eight lanes per signature
         t.test_mixed_key_types_one_batch(eng, orc)
         t.test_signature_rounds(eng, orc)
         t.test_limits_and_large_header_blocks_parity(eng, orc)

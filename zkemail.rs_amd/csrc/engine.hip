@@ -84,8 +84,10 @@ struct zke_engine {
   int sha_tile = SHA_TILE;
   int dfa_wave = 1;                 // regex parts: one e-mail per wave with a chunk map (ZKE_DFA_WAVE=0: one e-mail per lane)
   size_t dfa_wave_lds_attr = 0;
+  uint64_t batch_key_total = 0;     // key bytes of the batch being run: > 272 per e-mail -> some modulus is above 2048 bits
   int rsa_quad = -1;                // four-lanes-per-signature RSA kernel (rsa_quad.hip.h): -1 by batch size, 0 never, 1 always (ZKE_RSA_QUAD)
   uint32_t rsa_quad_min = 2048;     // -1: batches of at least this many e-mails (ZKE_RSA_QUAD_MIN)
+  uint32_t rsa_oct_min = 1024;      // ... for the eight-lane form of moduli above 2048 bits (ZKE_RSA_OCT_MIN)
   int sha_pair = -1;                // two-wave SHA-256 kernel: -1 by launch size, 0 never, 1 always (ZKE_SHA_PAIR)
   bool front_attr_set = false;
   bool wave_parse = true;           // front end: one e-mail per wavefront (parse.hip.h); ZKE_LANE_PARSE=1 selects the
@@ -157,16 +159,24 @@ int launch_rsa(zke_engine* e, const RsaJob* jobs, uint32_t n, const uint8_t* has
   if (n == 0) return 0;
   const uint32_t grid = n;
   KeyCacheEntry* cache = key_hash_base ? e->key_cache.as<KeyCacheEntry>() : nullptr;
-  (void)any_big;
   // Moduli of up to 2048 bits with e = 65537 and cached key constants go to the four-lanes-per-signature kernel
   // (rsa_quad.hip.h); the one-signature-per-wave kernel runs first, fills the key cache, marks those jobs and does the rest.
   // Its waves carry 16 signatures through one ~95 k-instruction chain (alone: 220 us per launch instead of 52), so it pays
   // when a launch has enough of them to fill the chip: 8 192 e-mails per batch +27 %, 4 096 +19 %, 1 024 -16 %.
-  const bool want_quad = e->rsa_quad > 0 || (e->rsa_quad < 0 && n >= e->rsa_quad_min);
-  const uint32_t quad = (cache && fin.b.results && want_quad) ? 1u : 0u;
+  // The eight-lane form replaces a much slower kernel (46 k instructions per RSA-4096 signature) and pays from 1 024 per batch
+  // (+17 %; 2 048: +50 %; 512: -28 %).  Bit 0: four lanes (<= 2048 bits), bit 1: eight lanes (2049..4096 bits).
+  uint32_t quad = 0;
+  if (cache && fin.b.results) {
+    if (e->rsa_quad > 0 || (e->rsa_quad < 0 && n >= e->rsa_quad_min)) quad |= 1u;
+    // any_big (the caller's hint: the batch's keys average more than an RSA-2048 key) gates the eight-lane launch; without it
+    // the pre-pass keeps large moduli for itself, so the two always agree
+    if (any_big && (e->rsa_quad > 0 || (e->rsa_quad < 0 && n >= e->rsa_oct_min))) quad |= 2u;
+  }
   hipLaunchKernelGGL(rsa_verify_kernel, dim3(grid), dim3(64), 0, s, jobs, n, hash_base, hash_stride, ok, em, cache, key_hash_base, fin, quad);
-  if (quad)
-    hipLaunchKernelGGL(rsa_quad_kernel, dim3((n + 15) / 16), dim3(64), 0, s, jobs, n, hash_base, hash_stride, ok, em, cache, key_hash_base, fin);
+  if (quad & 1u)
+    hipLaunchKernelGGL(rsa_group_kernel<4>, dim3((n + 15) / 16), dim3(64), 0, s, jobs, n, hash_base, hash_stride, ok, em, cache, key_hash_base, fin);
+  if (quad & 2u)
+    hipLaunchKernelGGL(rsa_group_kernel<8>, dim3((n + 7) / 8), dim3(64), 0, s, jobs, n, hash_base, hash_stride, ok, em, cache, key_hash_base, fin);
   HIPCHK(e, hipGetLastError());
   return 0;
 }
@@ -211,6 +221,7 @@ int zke_engine_create(const zke_options* opt, zke_engine** out) {
   if (const char* sp = getenv("ZKE_SHA_PAIR")) e->sha_pair = atoi(sp);
   if (const char* rq = getenv("ZKE_RSA_QUAD")) e->rsa_quad = atoi(rq);
   if (const char* rm = getenv("ZKE_RSA_QUAD_MIN")) e->rsa_quad_min = (uint32_t)atoi(rm);
+  if (const char* ro = getenv("ZKE_RSA_OCT_MIN")) e->rsa_oct_min = (uint32_t)atoi(ro);
   if (const char* dw = getenv("ZKE_DFA_WAVE")) e->dfa_wave = atoi(dw);
   if (getenv("ZKE_DEBUG_SKIP_RSA")) e->debug_skip_rsa = 1;
   if (getenv("ZKE_DEBUG_SKIP_ED")) e->debug_skip_ed = 1;

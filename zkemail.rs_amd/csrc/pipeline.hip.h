@@ -89,7 +89,8 @@ int run_device_pipeline(zke_engine* e, const zke_batch* in, uint64_t raw_total, 
     }
     FinArgs fa{B, round, rounds, e->pending.as<uint32_t>(), e->debug_skip_rsa};
     if ((r = launch_rsa(e, B.rsa, n, reinterpret_cast<const uint8_t*>(out_dev) + offsetof(zke_result, header_hash),
-                        sizeof(zke_result), nullptr, want_em ? e->em_dbg.as<uint8_t>() : nullptr, s, true,
+                        sizeof(zke_result), nullptr, want_em ? e->em_dbg.as<uint8_t>() : nullptr, s,
+                        e->batch_key_total > (uint64_t)n * 272 /* an RSA-2048 key is 270 bytes of DER: some key is larger */,
                         e->key_cache.p ? reinterpret_cast<const uint8_t*>(out_dev) + offsetof(zke_result, public_key_hash) : nullptr, fa)))
       return r;
     if (round == 0) { tm.mark(); tm.mark(); }      // RSA + verdict are one launch now (finalize_us reads 0)
@@ -356,7 +357,8 @@ int zke_dfa_register(zke_engine* e, const uint8_t* fwd, size_t fwd_len, const ui
 
 int zke_verify_batch_device(zke_engine* e, const zke_batch* in, uint64_t raw_total, uint64_t domain_total, uint64_t key_total,
                             zke_result* out_dev, void* stream) {
-  (void)domain_total; (void)key_total;
+  (void)domain_total;
+  e->batch_key_total = key_total;
   if (!e || !in || (in->n && (!out_dev || !in->raw_blob || !in->raw_off || !in->domain_off || !in->key_off || !in->key_type)))
     return ZKE_E_ARG;
   HIPCHK(e, hipSetDevice(e->device));
@@ -381,6 +383,7 @@ int zke_verify_batch(zke_engine* e, const zke_batch* in, zke_result* out, zke_de
   hipStream_t s = e->stream;
   const uint64_t raw_total = in->raw_off[n] - in->raw_off[0], dom_total = in->domain_off[n] - in->domain_off[0],
                  key_total = in->key_off[n] - in->key_off[0];
+  e->batch_key_total = key_total;
   const uint32_t P = in->with_regex ? in->n_header_parts + in->n_body_parts : 0;
   const bool caps = P && in->cap_off;
   const uint32_t n_caps = caps ? in->cap_off[(size_t)n * P] : 0;

@@ -38,7 +38,8 @@ static_assert(sizeof(RsaJob) == 1056, "RsaJob layout");
 enum : uint32_t {
   RSA_F_ACTIVE = 1,             // run the modexp
   RSA_F_SHA1 = 2,               // EMSA block carries the SHA-1 DigestInfo and a 20-byte hash (a=rsa-sha1)
-  RSA_F_QUAD = 4,               // set by rsa_verify_kernel: rsa_quad_kernel (four lanes per signature) takes this job
+  RSA_F_QUAD = 4,               // set by rsa_verify_kernel: rsa_group_kernel<4> (four lanes per signature) takes this job
+  RSA_F_OCT = 8,                // ... rsa_group_kernel<8> (eight lanes per signature: moduli of 2049..4096 bits)
 };
 
 // Per-key Montgomery constants, cached across e-mails and batches.  An entry is claimed once
@@ -52,9 +53,9 @@ struct KeyCacheEntry {
   uint32_t pad;
   uint32_t hash[8];             // SHA-256 of the DER key (zke_result.public_key_hash)
   uint32_t rr[128];             // R^2 mod n, limb q*64+lane
-  uint32_t rr28[76];            // moduli of 512..2048 bits: 2^4256 mod n as 76 limbs of 28 bits (rsa_quad.hip.h)
+  uint32_t rr28[152];           // rsa_quad.hip.h: 2^4256 mod n as 76 limbs of 28 bits (512..2048 bits), 2^8512 mod n as 152 (..4096)
 };
-static_assert(sizeof(KeyCacheEntry) == 864, "KeyCacheEntry layout");
+static_assert(sizeof(KeyCacheEntry) == 1168, "KeyCacheEntry layout");
 constexpr uint32_t KEY_CACHE_SLOTS = 4096;
 
 // ---- cross-lane helpers -------------------------------------------------------------

@@ -13,7 +13,7 @@ __device__ __forceinline__ void rsa_wave(const RsaJob* __restrict__ jobs, uint32
                                          const uint8_t* __restrict__ hash_base, size_t hash_stride,
                                          uint32_t* __restrict__ ok_out, uint8_t* __restrict__ em_out,
                                          KeyCacheEntry* cache, const uint8_t* __restrict__ key_hash_base,
-                                         const FinArgs& fin, bool quad) {
+                                         const FinArgs& fin, uint32_t quad) {
   const int lane = threadIdx.x & 63;
   const RsaJob* J = jobs + job;
   const uint32_t flags = J->flags, k = J->k, bits = J->bits;
@@ -40,7 +40,8 @@ __device__ __forceinline__ void rsa_wave(const RsaJob* __restrict__ jobs, uint32
     const uint32_t* kh = nullptr;
     // Pre-pass for rsa_quad_kernel: e = 65537, 512..2048 bits and the key's constants in the cache (found there, or put
     // there by this wave) -> the job is marked and left to that kernel, verdict included.
-    const bool quad_ok = quad && NL == 1 && cache && fin.b.results && bits >= 512 && J->e == 65537;
+    const bool quad_ok = (quad & (NL == 1 ? 1u : 2u)) && cache && fin.b.results && bits >= 512 && J->e == 65537;
+    constexpr uint32_t GROUP_FLAG = NL == 1 ? RSA_F_QUAD : RSA_F_OCT;
     if (cache) {
       kh = (const uint32_t*)(key_hash_base + (size_t)job * hash_stride);
       E = cache + (kh[0] % KEY_CACHE_SLOTS);
@@ -60,7 +61,7 @@ __device__ __forceinline__ void rsa_wave(const RsaJob* __restrict__ jobs, uint32
       }
     }
     if (hit && quad_ok) {
-      if (lane == 0) const_cast<RsaJob*>(J)->flags = flags | RSA_F_QUAD;
+      if (lane == 0) const_cast<RsaJob*>(J)->flags = flags | GROUP_FLAG;
       return;
     }
     if (!hit) {
@@ -98,28 +99,33 @@ __device__ __forceinline__ void rsa_wave(const RsaJob* __restrict__ jobs, uint32
           if (lane == 0) { st(&E->ninv, ninv); st(&E->bits, bits); }
 #pragma unroll
           for (int q = 0; q < NL; q++) st(&E->rr[q * 64 + lane], rr.v[q]);
-          if constexpr (NL == 1) {
-            if (bits >= 512) {
-              // 2^4256 mod n for the 28-bit radix of rsa_quad.hip.h (R' = 2^2128): two more products with R = 2^2048,
-              // mont(2^4096, 2^160) = 2^2208, mont(2^4096, 2^2208) = 2^4256; then limb t = bits [28 t, 28 t + 28)
-              Big<1> c160, z, r2;
-              c160.v[0] = lane == 5 ? 1u : 0u;
-              mont_mul<1>(z, rr, c160, nn, ninv, lane);
-              mont_mul<1>(r2, rr, z, nn, ninv, lane);
-              for (uint32_t t0 = 0; t0 < 128; t0 += 64) {
-                const uint32_t t = t0 + (uint32_t)lane, bit = 28u * t, w = bit >> 5;
-                const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4 * (w & 63)), (int)r2.v[0]);
-                uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4 * ((w + 1) & 63)), (int)r2.v[0]);
-                if (w + 1 >= 64) hi = 0;
-                const uint32_t v = w < 64 ? (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (bit & 31)) & 0x0FFFFFFFu : 0u;
-                if (t < 76) st(&E->rr28[t], v);
+          if (bits >= 512) {
+            // R'^2 mod n for the 28-bit radix of rsa_quad.hip.h (R' = 2^(532 G): 2^2128 for four lanes, 2^4256 for eight):
+            // two more products with R = 2^(2048 NL): mont(R^2, 2^c) = 2^c R, mont(R^2, 2^c R) = 2^c R^2 with
+            // c = 2 (532 G - 2048 NL) = 160 / 320; then limb t = bits [28 t, 28 t + 28)
+            Big<NL> cc, z, r2;
+#pragma unroll
+            for (int q = 0; q < NL; q++) cc.v[q] = (q == 0 && lane == (NL == 1 ? 5 : 10)) ? 1u : 0u;
+            mont_mul<NL>(z, rr, cc, nn, ninv, lane);
+            mont_mul<NL>(r2, rr, z, nn, ninv, lane);
+            for (uint32_t t0 = 0; t0 < 64u * (NL + 1); t0 += 64) {
+              const uint32_t t = t0 + (uint32_t)lane, bit = 28u * t, w = bit >> 5;
+              uint32_t lo = 0, hi = 0;
+#pragma unroll
+              for (int q = 0; q < NL; q++) {                       // 32-bit limb w lives in v[w >> 6] of lane w & 63
+                const uint32_t l0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4 * (w & 63)), (int)r2.v[q]);
+                const uint32_t l1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4 * ((w + 1) & 63)), (int)r2.v[q]);
+                if ((w >> 6) == (uint32_t)q) lo = l0;
+                if (((w + 1) >> 6) == (uint32_t)q) hi = l1;
               }
+              const uint32_t v = (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (bit & 31)) & 0x0FFFFFFFu;
+              if (t < 76u * NL) st(&E->rr28[t], v);
             }
           }
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the entry has reached the coherence point ...
           if (lane == 0) st(&E->state, 2u);                        // ... before it is published
           if (quad_ok) {
-            if (lane == 0) const_cast<RsaJob*>(J)->flags = flags | RSA_F_QUAD;
+            if (lane == 0) const_cast<RsaJob*>(J)->flags = flags | GROUP_FLAG;
             return;
           }
         }
@@ -177,8 +183,8 @@ __global__ __launch_bounds__(64, 6) void rsa_verify_kernel(const RsaJob* __restr
   if (job >= n) return;
   if (fin.b.results && fin.b.meta[job].state == ST_PENDING) return;     // waits for a later signature round
   const uint32_t bits = __builtin_amdgcn_readfirstlane(jobs[job].bits);
-  if (bits <= 2048) rsa_wave<1>(jobs, job, hash_base, hash_stride, ok_out, em_out, cache, key_hash_base, fin, quad != 0);
-  else rsa_wave<2>(jobs, job, hash_base, hash_stride, ok_out, em_out, cache, key_hash_base, fin, false);
+  if (bits <= 2048) rsa_wave<1>(jobs, job, hash_base, hash_stride, ok_out, em_out, cache, key_hash_base, fin, quad);
+  else rsa_wave<2>(jobs, job, hash_base, hash_stride, ok_out, em_out, cache, key_hash_base, fin, quad);
 }
 
 }  // namespace zke

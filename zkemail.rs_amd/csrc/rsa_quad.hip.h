@@ -1,6 +1,6 @@
 // rsa_quad.hip.h — RSA verification with FOUR LANES PER SIGNATURE (16 signatures per wavefront) for moduli of up
 // to 2048 bits and e = 65537: the same rsa 0.9.6 / num-bigint-dig operation as rsa.hip.h (call site
-// core/src/email.rs:31-33; RFC 8017 §8.2.2, §9.2), 2.4x fewer VALU instructions per signature.
+// core/src/email.rs:31-33; RFC 8017 §8.2.2, §9.2), half the VALU instructions per signature.
 //
 // Why.  The path is VALU-issue bound and the one-limb-per-lane kernel spends 9 instructions per
 // limb and CIOS step: two multiplies, and seven to read the multiplier digit, form the quotient digit, shift the
@@ -15,9 +15,10 @@
 //     becomes the low half: 19 quad rotations + 19 additions per 722 multiplies;
 //   * R = 2^2128 > 4n, so values stay in [0, 2n) without any conditional subtraction; carries are normalised once per
 //     product (limbs <= 2^28), exactly only for the final result.
-// 46 instructions per step for 16 signatures instead of 9 per step for one.
+// 60 instructions per step for 16 signatures instead of 9 per step for one.  Moduli of 2049..4096 bits run the same
+// code with eight lanes per signature (152 limbs, R = 2^4256, eight blocks of 19 steps).
 //
-// R^2 mod n for this radix (2^4256 mod n) comes from the key cache: rsa_verify_kernel runs first as a pre-pass, fills
+// R^2 mod n for this radix (2^4256 mod n; 2^8512 mod n for eight lanes) comes from the key cache: rsa_verify_kernel runs first as a pre-pass, fills
 // the entry of a key it sees for the first time (two more 32-bit Montgomery products turn 2^4096 mod n into
 // 2^4256 mod n) and marks the jobs this kernel takes with RSA_F_QUAD; everything else — other exponents, moduli above
 // 2048 bits, keys whose cache slot belongs to another key, signatures rsa 0.9.6 rejects before the arithmetic —
@@ -28,53 +29,61 @@
 namespace zke {
 
 constexpr int QL = 19;                       // limbs per lane
-constexpr int QLIMBS = 4 * QL;               // 76 limbs of 28 bits: 2128 bits
 constexpr uint32_t QMASK = 0x0FFFFFFFu;
-struct QBig { uint32_t v[QL]; };             // lane p of the quad: limbs 19p .. 19p+18
+struct QBig { uint32_t v[QL]; };             // lane p of the group: limbs 19p .. 19p+18
 
-__device__ __forceinline__ uint32_t q_bcast0(uint32_t x) {       // lane 0 of the quad to all four
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x00 /*quad_perm:[0,0,0,0]*/, 0xf, 0xf, false);
+// Lane groups of G = 4 (one DPP quad: 76 limbs, moduli <= 2048 bits) or G = 8 (half a DPP row: 152 limbs, <= 4096 bits).
+template <int G> __device__ __forceinline__ uint32_t g_bcast0(uint32_t x) {        // lane 0 of the group to all of it
+  uint32_t q = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x00 /*quad_perm:[0,0,0,0]*/, 0xf, 0xf, false);
+  if (G == 8) q = (uint32_t)__builtin_amdgcn_update_dpp((int)q, (int)q, 0x114 /*row_shr:4*/, 0xf, 0xA /*lanes 4-7, 12-15*/, false);
+  return q;
 }
-__device__ __forceinline__ uint32_t q_rotdown(uint32_t x) {      // lane p <- lane p+1, lane 3 <- lane 0
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x39 /*quad_perm:[1,2,3,0]*/, 0xf, 0xf, false);
+template <int G> __device__ __forceinline__ uint32_t g_rotdown(uint32_t x, int p) {   // lane p <- lane p+1, lane G-1 <- lane 0
+  if (G == 4) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x39 /*quad_perm:[1,2,3,0]*/, 0xf, 0xf, false);
+  const uint32_t a = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x101 /*row_shl:1*/, 0xf, 0xf, false);
+  const uint32_t b = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x117 /*row_shr:7*/, 0xf, 0xf, false);
+  return p == 7 ? b : a;
 }
-__device__ __forceinline__ uint32_t q_fromprev(uint32_t x) {     // lane p <- lane p-1 (lane 0 keeps its own: callers mask it)
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x90 /*quad_perm:[0,0,1,2]*/, 0xf, 0xf, false);
+template <int G> __device__ __forceinline__ uint32_t g_fromprev(uint32_t x) {      // lane p <- lane p-1 (lane 0: callers mask it)
+  if (G == 4) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x90 /*quad_perm:[0,0,1,2]*/, 0xf, 0xf, false);
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111 /*row_shr:1*/, 0xf, 0xf, false);
 }
 
-// W = (a * b + sum_i m_i * n * 2^(28 i)) / 2^2128 as 19 lazy 64-bit columns per lane (column j of lane p: limb 19p + j)
-__device__ __forceinline__ void qmont_columns(uint64_t (&W)[2 * QL], const QBig& a, const QBig& b, const QBig& n, uint32_t ninv) {
+// W = (a * b + sum_i m_i * n * 2^(28 i)) / 2^(532 G) as 19 lazy 64-bit columns per lane (column j of lane p: limb 19p + j).
+// A register holds at most 38 products (< 2^56 each) in its life as a high and then a low column: no overflow.
+template <int G>
+__device__ __forceinline__ void qmont_columns(uint64_t (&W)[2 * QL], const QBig& a, const QBig& b, const QBig& n, uint32_t ninv, int p) {
 #pragma unroll
   for (int j = 0; j < 2 * QL; j++) W[j] = 0;
   QBig B = b;
 #pragma unroll 1
-  for (int blk = 0; blk < 4; blk++) {
-    // 19 steps: multiplier digits 19 blk + r, held by lane 0 of the quad after blk rotations of B
+  for (int blk = 0; blk < G; blk++) {
+    // 19 steps: multiplier digits 19 blk + r, held by lane 0 of the group after blk rotations of B
 #pragma unroll
     for (int r = 0; r < QL; r++) {
-      const uint32_t bd = q_bcast0(B.v[r]);
+      const uint32_t bd = g_bcast0<G>(B.v[r]);
 #pragma unroll
       for (int k = 0; k < QL; k++) W[k + r] = (uint64_t)a.v[k] * bd + W[k + r];
-      const uint32_t m = q_bcast0(((uint32_t)W[r] * ninv) & QMASK);          // lane 0's column r is the lowest live limb
+      const uint32_t m = g_bcast0<G>(((uint32_t)W[r] * ninv) & QMASK);       // lane 0's column r is the lowest live limb
 #pragma unroll
       for (int k = 0; k < QL; k++) W[k + r] = (uint64_t)n.v[k] * m + W[k + r];
       W[r + 1] += W[r] >> 28;              // lane 0: the column is now a multiple of 2^28; other lanes: a partial carry
       W[r] &= QMASK;
     }
-    // the window moves up 19 limbs: finished low columns go one lane down (lane 0's are zero and reach lane 3)
+    // the window moves up 19 limbs: finished low columns go one lane down (lane 0's are zero and reach the top lane)
 #pragma unroll
     for (int j = 0; j < QL; j++) {
-      const uint32_t recv = q_rotdown((uint32_t)W[j]);
+      const uint32_t recv = g_rotdown<G>((uint32_t)W[j], p);
       W[j] = W[QL + j] + recv;
       W[QL + j] = 0;
     }
 #pragma unroll
-    for (int r = 0; r < QL; r++) B.v[r] = q_rotdown(B.v[r]);
+    for (int r = 0; r < QL; r++) B.v[r] = g_rotdown<G>(B.v[r], p);
   }
 }
 
-// columns -> limbs.  CROSS cross-lane passes: 1 leaves limbs <= 2^28 (good enough as an operand), 3 is exact.
-template <int CROSS>
+// columns -> limbs.  CROSS cross-lane passes: 1 leaves limbs <= 2^28 (good enough as an operand), G - 1 is exact.
+template <int G, int CROSS>
 __device__ __forceinline__ void qnorm(QBig& out, const uint64_t (&W)[2 * QL], int p) {
   uint64_t c = 0;
 #pragma unroll
@@ -86,7 +95,7 @@ __device__ __forceinline__ void qnorm(QBig& out, const uint64_t (&W)[2 * QL], in
   uint32_t clo = (uint32_t)c, chi = (uint32_t)(c >> 32);       // < 2^37 out of the local pass
 #pragma unroll
   for (int pass = 0; pass < CROSS; pass++) {
-    uint32_t ilo = q_fromprev(clo), ihi = q_fromprev(chi);
+    uint32_t ilo = g_fromprev<G>(clo), ihi = g_fromprev<G>(chi);
     if (p == 0) { ilo = 0; ihi = 0; }
     const uint64_t t0 = (uint64_t)out.v[0] + (((uint64_t)ihi << 32) | ilo);
     out.v[0] = (uint32_t)t0 & QMASK;
@@ -99,31 +108,32 @@ __device__ __forceinline__ void qnorm(QBig& out, const uint64_t (&W)[2 * QL], in
     }
     clo = c32; chi = 0;                                         // 0 or 1 from here on
   }
-  uint32_t last = q_fromprev(clo);
+  uint32_t last = g_fromprev<G>(clo);
   if (p == 0) last = 0;
-  out.v[0] += last;                                             // value-preserving; zero after three passes
+  out.v[0] += last;                                             // value-preserving; zero after G - 1 passes
 }
 
-struct QuadLds { uint32_t limb[16][QLIMBS + 4]; };
-
-__global__ __launch_bounds__(64) void rsa_quad_kernel(const RsaJob* __restrict__ jobs, uint32_t n,
-                                                      const uint8_t* __restrict__ hash_base, size_t hash_stride,
-                                                      uint32_t* __restrict__ ok_out, uint8_t* __restrict__ em_out,
-                                                      const KeyCacheEntry* cache, const uint8_t* __restrict__ key_hash_base,
-                                                      FinArgs fin) {
-  __shared__ QuadLds L;
+template <int G>
+__global__ __launch_bounds__(64) void rsa_group_kernel(const RsaJob* __restrict__ jobs, uint32_t n,
+                                                       const uint8_t* __restrict__ hash_base, size_t hash_stride,
+                                                       uint32_t* __restrict__ ok_out, uint8_t* __restrict__ em_out,
+                                                       const KeyCacheEntry* cache, const uint8_t* __restrict__ key_hash_base,
+                                                       FinArgs fin) {
+  constexpr int NG = 64 / G, LIMBS = G * QL;
+  constexpr uint32_t MY_FLAG = G == 4 ? RSA_F_QUAD : RSA_F_OCT;
+  __shared__ uint32_t Llimb[NG][LIMBS + 4];
 #ifndef ZKE_QUAD_PRIO
 #define ZKE_QUAD_PRIO 3
 #endif
-  // 16 signatures share one long dependency chain (~95 k instructions): served round-robin with the short waves of other
-  // batches it would stretch several times over and hold its whole batch back; the others have parallel slack.
+  // NG signatures share one long dependency chain (~95 k instructions for G = 4): served round-robin with the short waves
+  // of other batches it would stretch several times over and hold its whole batch back; the others have parallel slack.
   __builtin_amdgcn_s_setprio(ZKE_QUAD_PRIO);
-  const int lane = threadIdx.x & 63, p = lane & 3, qd = lane >> 2;
-  const uint32_t job = blockIdx.x * 16 + qd;
+  const int lane = threadIdx.x & 63, p = lane & (G - 1), grp = lane / G;
+  const uint32_t job = blockIdx.x * NG + grp;
   const RsaJob* J = jobs + (job < n ? job : 0);
   uint32_t flags = 0;
   if (job < n) flags = J->flags;
-  const bool act = (flags & RSA_F_QUAD) != 0;
+  const bool act = (flags & MY_FLAG) != 0;
   if (__ballot(act) == 0) return;
 
   QBig nn, s, rr;
@@ -133,8 +143,10 @@ __global__ __launch_bounds__(64) void rsa_quad_kernel(const RsaJob* __restrict__
   if (act) {
     typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
     auto limb_of = [&](const uint8_t* field, uint32_t t) -> uint32_t {     // bits [28 t, 28 t + 28) of a big-endian 512-byte field
-      const uint32_t bit = 28u * t, o = bit >> 3;
-      const uint64_t v = __builtin_bswap64(*(const u64_unaligned*)(field + 504 - o));
+      const uint32_t bit = 28u * t, o = bit >> 3;                          // little-endian byte o = field[511 - o]
+      if (o >= 512) return 0;                                              // beyond 4096 bits
+      const uint32_t oo = o > 504 ? 504u : o;                              // the top limbs: read the field's first 8 bytes and shift
+      const uint64_t v = __builtin_bswap64(*(const u64_unaligned*)(field + 504 - oo)) >> (8 * (o - oo));
       return (uint32_t)(v >> (bit & 7)) & QMASK;
     };
     const uint32_t* kh = (const uint32_t*)(key_hash_base + (size_t)job * hash_stride);
@@ -158,22 +170,22 @@ __global__ __launch_bounds__(64) void rsa_quad_kernel(const RsaJob* __restrict__
     QBig b;
 #pragma unroll
     for (int j = 0; j < QL; j++) b.v[j] = step == 0 ? rr.v[j] : (step == 17 ? xm.v[j] : acc.v[j]);
-    qmont_columns(W, acc, b, nn, ninv);
-    qnorm<1>(acc, W, p);
+    qmont_columns<G>(W, acc, b, nn, ninv, p);
+    qnorm<G, 1>(acc, W, p);
     if (step == 0) xm = acc;
   }
   {
     QBig one;
 #pragma unroll
     for (int j = 0; j < QL; j++) one.v[j] = (j == 0 && p == 0) ? 1u : 0u;
-    qmont_columns(W, acc, one, nn, ninv);
-    qnorm<3>(acc, W, p);                      // EM, exact: < n
+    qmont_columns<G>(W, acc, one, nn, ninv, p);
+    qnorm<G, G - 1>(acc, W, p);               // EM, exact: < n
   }
 
   // EMSA-PKCS1-v1_5 compare (rsa 0.9.6 pkcs1v15_sign_unpad), byte by byte through LDS
 #pragma unroll
-  for (int j = 0; j < QL; j++) L.limb[qd][QL * p + j] = acc.v[j];
-  L.limb[qd][QLIMBS + p] = 0;
+  for (int j = 0; j < QL; j++) Llimb[grp][QL * p + j] = acc.v[j];
+  if (p < 4) Llimb[grp][LIMBS + p] = 0;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   const bool sha1 = (flags & RSA_F_SHA1) != 0;
@@ -181,25 +193,26 @@ __global__ __launch_bounds__(64) void rsa_quad_kernel(const RsaJob* __restrict__
   if (act) {
     const uint32_t* hw = (const uint32_t*)(hash_base + (size_t)job * hash_stride);
     for (uint32_t u = 0; u < 64; u++) {
-      const uint32_t i = 4 * u + (uint32_t)p;                    // little-endian byte index
+      const uint32_t i = G * u + (uint32_t)p;                    // little-endian byte index: 64 G bytes per group
       const uint32_t t = (8 * i) / 28, sh = 8 * i - 28 * t;
-      const uint64_t two = (uint64_t)L.limb[qd][t] | ((uint64_t)L.limb[qd][t + 1] << 28);
+      const uint64_t two = (uint64_t)Llimb[grp][t] | ((uint64_t)Llimb[grp][t + 1] << 28);
       const uint32_t got = (uint32_t)(two >> sh) & 0xff;
       bad = bad || got != emsa_byte(i, kbytes, hw, sha1);
       if (em_out) em_out[(size_t)job * 512 + 511 - i] = (uint8_t)got;
     }
-    if (em_out) {
+    if (em_out && G == 4) {
 #pragma unroll
       for (int z = 0; z < 16; z++) *(uint32_t*)(em_out + (size_t)job * 512 + 64 * p + 4 * z) = 0;     // upper half of the slot
     }
   }
   const uint64_t badm = __ballot(bad);
-  const bool ok = act && ((badm >> (4 * qd)) & 0xF) == 0 && kbytes >= (sha1 ? 46u : 62u);      // k >= tLen + 11
+  const uint64_t gmask = (G == 4 ? 0xFull : 0xFFull);
+  const bool ok = act && ((badm >> (G * grp)) & gmask) == 0 && kbytes >= (sha1 ? 46u : 62u);      // k >= tLen + 11
   if (act && p == 0 && ok_out) ok_out[job] = ok ? 1u : 0u;
   if (fin.b.results) {
     const uint64_t actm = __ballot(act && p == 0), okm = __ballot(ok && p == 0);
-    for (int q2 = 0; q2 < 16; q2++)
-      if ((actm >> (4 * q2)) & 1) verdict_wave(fin, blockIdx.x * 16 + q2, ((okm >> (4 * q2)) & 1) != 0, lane);
+    for (int g2 = 0; g2 < NG; g2++)
+      if ((actm >> (G * g2)) & 1) verdict_wave(fin, blockIdx.x * NG + g2, ((okm >> (G * g2)) & 1) != 0, lane);
   }
 }
 
