@@ -161,7 +161,7 @@ int launch_rsa(zke_engine* e, const RsaJob* jobs, uint32_t n, const uint8_t* has
   KeyCacheEntry* cache = key_hash_base ? e->key_cache.as<KeyCacheEntry>() : nullptr;
   // Moduli of up to 2048 bits with e = 65537 and cached key constants go to the four-lanes-per-signature kernel
   // (rsa_quad.hip.h); the one-signature-per-wave kernel runs first, fills the key cache, marks those jobs and does the rest.
-  // Its waves carry 16 signatures through one ~95 k-instruction chain (alone: 220 us per launch instead of 52), so it pays
+  // Its waves carry 16 signatures through one ~95 k-instruction chain (alone: 210 us per launch instead of 52), so it pays
   // when a launch has enough of them to fill the chip: 8 192 e-mails per batch +27 %, 4 096 +19 %, 1 024 -16 %.
   // The eight-lane form replaces a much slower kernel (46 k instructions per RSA-4096 signature) and pays from 1 024 per batch
   // (+17 %; 2 048: +50 %; 512: -28 %).  Bit 0: four lanes (<= 2048 bits), bit 1: eight lanes (2049..4096 bits).

@@ -15,7 +15,7 @@
 //     becomes the low half: 19 quad rotations + 19 additions per 722 multiplies;
 //   * R = 2^2128 > 4n, so values stay in [0, 2n) without any conditional subtraction; carries are normalised once per
 //     product (limbs <= 2^28), exactly only for the final result.
-// 60 instructions per step for 16 signatures instead of 9 per step for one.  Moduli of 2049..4096 bits run the same
+// 55 instructions per step for 16 signatures instead of 9 per step for one.  Moduli of 2049..4096 bits run the same
 // code with eight lanes per signature (152 limbs, R = 2^4256, eight blocks of 19 steps).
 //
 // R^2 mod n for this radix (2^4256 mod n; 2^8512 mod n for eight lanes) comes from the key cache: rsa_verify_kernel runs first as a pre-pass, fills
@@ -33,20 +33,21 @@ constexpr uint32_t QMASK = 0x0FFFFFFFu;
 struct QBig { uint32_t v[QL]; };             // lane p of the group: limbs 19p .. 19p+18
 
 // Lane groups of G = 4 (one DPP quad: 76 limbs, moduli <= 2048 bits) or G = 8 (half a DPP row: 152 limbs, <= 4096 bits).
+// (bound_ctrl on the full-mask moves: lanes without a source read 0 and the destination needs no initial value)
 template <int G> __device__ __forceinline__ uint32_t g_bcast0(uint32_t x) {        // lane 0 of the group to all of it
-  uint32_t q = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x00 /*quad_perm:[0,0,0,0]*/, 0xf, 0xf, false);
+  uint32_t q = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x00 /*quad_perm:[0,0,0,0]*/, 0xf, 0xf, true);
   if (G == 8) q = (uint32_t)__builtin_amdgcn_update_dpp((int)q, (int)q, 0x114 /*row_shr:4*/, 0xf, 0xA /*lanes 4-7, 12-15*/, false);
   return q;
 }
 template <int G> __device__ __forceinline__ uint32_t g_rotdown(uint32_t x, int p) {   // lane p <- lane p+1, lane G-1 <- lane 0
-  if (G == 4) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x39 /*quad_perm:[1,2,3,0]*/, 0xf, 0xf, false);
-  const uint32_t a = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x101 /*row_shl:1*/, 0xf, 0xf, false);
-  const uint32_t b = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x117 /*row_shr:7*/, 0xf, 0xf, false);
+  if (G == 4) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x39 /*quad_perm:[1,2,3,0]*/, 0xf, 0xf, true);
+  const uint32_t a = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x101 /*row_shl:1*/, 0xf, 0xf, true);
+  const uint32_t b = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x117 /*row_shr:7*/, 0xf, 0xf, true);
   return p == 7 ? b : a;
 }
 template <int G> __device__ __forceinline__ uint32_t g_fromprev(uint32_t x) {      // lane p <- lane p-1 (lane 0: callers mask it)
-  if (G == 4) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x90 /*quad_perm:[0,0,1,2]*/, 0xf, 0xf, false);
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111 /*row_shr:1*/, 0xf, 0xf, false);
+  if (G == 4) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x90 /*quad_perm:[0,0,1,2]*/, 0xf, 0xf, true);
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111 /*row_shr:1*/, 0xf, 0xf, true);
 }
 
 // W = (a * b + sum_i m_i * n * 2^(28 i)) / 2^(532 G) as 19 lazy 64-bit columns per lane (column j of lane p: limb 19p + j).
@@ -63,7 +64,8 @@ __device__ __forceinline__ void qmont_columns(uint64_t (&W)[2 * QL], const QBig&
     for (int r = 0; r < QL; r++) {
       const uint32_t bd = g_bcast0<G>(B.v[r]);
 #pragma unroll
-      for (int k = 0; k < QL; k++) W[k + r] = (uint64_t)a.v[k] * bd + W[k + r];
+      for (int k = 0; k < QL; k++)           // column r + 18 is touched here for the first time in this block (r > 0)
+        W[k + r] = (uint64_t)a.v[k] * bd + ((k == QL - 1 && r > 0) ? 0ull : W[k + r]);
       const uint32_t m = g_bcast0<G>(((uint32_t)W[r] * ninv) & QMASK);       // lane 0's column r is the lowest live limb
 #pragma unroll
       for (int k = 0; k < QL; k++) W[k + r] = (uint64_t)n.v[k] * m + W[k + r];
@@ -75,7 +77,6 @@ __device__ __forceinline__ void qmont_columns(uint64_t (&W)[2 * QL], const QBig&
     for (int j = 0; j < QL; j++) {
       const uint32_t recv = g_rotdown<G>((uint32_t)W[j], p);
       W[j] = W[QL + j] + recv;
-      W[QL + j] = 0;
     }
 #pragma unroll
     for (int r = 0; r < QL; r++) B.v[r] = g_rotdown<G>(B.v[r], p);
