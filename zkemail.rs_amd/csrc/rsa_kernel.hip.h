@@ -38,7 +38,7 @@ __device__ __forceinline__ void rsa_wave(const RsaJob* __restrict__ jobs, uint32
     bool hit = false;
     KeyCacheEntry* E = nullptr;
     const uint32_t* kh = nullptr;
-    // Pre-pass for rsa_quad_kernel: e = 65537, 512..2048 bits and the key's constants in the cache (found there, or put
+    // Pre-pass for rsa_group_kernel: e = 65537, 512..2048 bits and the key's constants in the cache (found there, or put
     // there by this wave) -> the job is marked and left to that kernel, verdict included.
     const bool quad_ok = (quad & (NL == 1 ? 1u : 2u)) && cache && fin.b.results && bits >= 512 && J->e == 65537;
     constexpr uint32_t GROUP_FLAG = NL == 1 ? RSA_F_QUAD : RSA_F_OCT;
