@@ -368,7 +368,7 @@ int zke_verify_batch_device(zke_engine* e, const zke_batch* in, uint64_t raw_tot
   // device mode runs a fixed number of signature rounds (options.reserved[1], default 1) without reading anything back
   const uint32_t rounds = e->device_mode_rounds;
   hipStream_t s = stream ? (hipStream_t)stream : e->stream;
-  // Launched eagerly: four kernels per batch.  (A hipGraph capture / replay of this sequence was tried in round 1:
+  // Launched eagerly: four kernels per batch (five or six when the lane-group RSA kernels take part: batches >= 2 048).  (A hipGraph capture / replay of this sequence was tried in round 1:
   // the eager path is not host-bound, and the replay faulted — it was removed rather than kept as a switch.)
   return run_device_pipeline(e, in, raw_total, out_dev, s, false, 0, rounds, rounds, true);
 }
