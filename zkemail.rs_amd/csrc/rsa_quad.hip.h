@@ -6,7 +6,7 @@
 // limb and CIOS step: two multiplies, and seven to read the multiplier digit, form the quotient digit, shift the
 // accumulator one lane down and keep its carries.  Here a number is 76 limbs of 28 bits, 19 consecutive limbs per
 // lane, four lanes (one DPP quad) per signature:
-//   * products of 28-bit limbs are < 2^56, and a column receives at most 152 of them per Montgomery product, so
+//   * products of 28-bit limbs are < 2^56, and a register holds at most 38 of them in its life as a column, so
 //     every column is a plain 64-bit accumulator: ONE v_mad_u64_u32 per limb product, no carry instructions;
 //   * the accumulator is a window of 38 columns per lane addressed at compile time (column k + r for limb k at
 //     step r of a block of 19 steps), so nothing is shifted inside a block; the per-step cross-lane work is two
@@ -18,11 +18,12 @@
 // 55 instructions per step for 16 signatures instead of 9 per step for one.  Moduli of 2049..4096 bits run the same
 // code with eight lanes per signature (152 limbs, R = 2^4256, eight blocks of 19 steps).
 //
-// R^2 mod n for this radix (2^4256 mod n; 2^8512 mod n for eight lanes) comes from the key cache: rsa_verify_kernel runs first as a pre-pass, fills
-// the entry of a key it sees for the first time (two more 32-bit Montgomery products turn 2^4096 mod n into
-// 2^4256 mod n) and marks the jobs this kernel takes with RSA_F_QUAD; everything else — other exponents, moduli above
-// 2048 bits, keys whose cache slot belongs to another key, signatures rsa 0.9.6 rejects before the arithmetic —
-// stays with the one-signature-per-wave path.
+// R^2 mod n for this radix (2^4256 mod n; 2^8512 mod n for eight lanes) comes from the key cache: rsa_verify_kernel
+// runs first as a pre-pass, fills the entry of a key it sees for the first time (two more 32-bit-radix Montgomery
+// products turn 2^4096 mod n into 2^4256 mod n) and marks the jobs these kernels take with RSA_F_QUAD / RSA_F_OCT;
+// everything else — other exponents, keys whose cache slot belongs to another key, signatures rsa 0.9.6 rejects before the
+// arithmetic — stays with the one-signature-per-wave path.  The algorithm and its register bounds are modelled with
+// Python integers in tests/test_rsa_group_model.py.
 #pragma once
 #include "rsa_kernel.hip.h"
 
