@@ -163,6 +163,15 @@ def main():
     g_steps = min(args.steps, n_slices)
     results_all = torch.zeros(n_slices * rec_bytes, dtype=torch.uint8, device=dev)
     gathered_all = torch.zeros(world * g_steps * wit_bytes, dtype=torch.uint8, device=dev) if use_dist else None
+    wit_local = torch.zeros(g_steps * wit_bytes, dtype=torch.uint8, device=dev) if use_dist else None
+
+    def exchange():
+        """Witnesses of this rank's steps (two strided copies into a preallocated buffer), then ONE all-gather."""
+        r = results_all[:g_steps * rec_bytes].view(-1, 192)
+        w = wit_local.view(-1, 72)
+        w[:, 0:8].copy_(r[:, 0:8])
+        w[:, 8:72].copy_(r[:, 32:96])
+        dist.all_gather_into_tensor(gathered_all, wit_local)
     eng = engines[0]
     stream_h = [streams[k].cuda_stream for k in range(S)]
     base_ptr = results_all.data_ptr()
@@ -182,13 +191,16 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if use_dist:
+        torch.cuda.synchronize()
+        exchange()                                    # untimed: first use of the copy kernels and of the communicator's all-gather
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     if use_dist:
         torch.cuda.synchronize()                      # every batch of this rank is done
-        dist.all_gather_into_tensor(gathered_all, D.witness_tensor(results_all[:g_steps * rec_bytes]))
+        exchange()
     fence()
     dt = time.perf_counter() - t0
     if use_dist:
