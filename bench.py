@@ -49,9 +49,28 @@ def parse_args():
     ap.add_argument("--no-saturated", action="store_true",
                     help="skip the chip-filling SHA-256 micro-benchmark (profile runs: keeps the kernel stats to the workload's launches)")
     ap.add_argument("--streams", type=int, default=20,
-                    help="batches in flight per GPU: step i runs on engine/stream i %% S (each engine owns its workspace); "
-                         "1 = strictly serial steps")
+                    help="submission slots of the engine = batches in flight per GPU: step i runs in slot i %% S (a stream and a "
+                         "workspace each; one engine, one key cache); 1 = strictly serial steps")
+    ap.add_argument("--alone-steps", type=int, default=8,
+                    help="steps of the extra pass that runs one batch at a time (per-kernel times of a batch alone); 0 = skip "
+                         "(profile runs: every launch in the trace is then an in-flight one)")
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks as children (torch.distributed.run) and pass rank 0's
+    JSON line through.  The parent has not touched the GPU — nothing is exec'ed from a process that initialised HIP."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, env=env)
+    raise SystemExit(r.returncode)
 
 
 def device_batch(torch, wl_batch, dev):
@@ -89,6 +108,8 @@ def device_batch(torch, wl_batch, dev):
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -103,7 +124,7 @@ def main():
 
     import zkemail_rs_amd as z
     from zkemail_rs_amd import _abi as A
-    from zkemail_rs_amd import synth
+    import synth
     from zkemail_rs_amd import distributed as D
 
     if not torch.cuda.is_available():
@@ -137,20 +158,20 @@ def main():
     else:
         wl = synth.make_workload(args.workload, seed=1000 + rank, **cfg)
     gen_s = time.time() - t0
-    S = max(1, args.streams)
-    # S independent batches in flight: one engine (workspace) + one HIP stream + one result buffer each.
-    # The inputs are read-only and shared.  A step is still one batch of n e-mails; consecutive steps
-    # simply do not wait for each other, as a service with a queue of batches would run them.
-    engines = [z.Engine(device=local_rank) for _ in range(S)]
+    S = max(1, min(args.streams, 64))
+    # ONE engine per GPU with S submission slots (a stream and a workspace each; the key cache, the DFA tables and the
+    # kernel attributes exist once).  S batches are in flight: a step is still one batch of n e-mails, consecutive steps
+    # simply do not wait for each other, as a service with a queue of batches would run them.  The inputs are read-only
+    # and shared.  zke_engine_reserve sizes every slot now: nothing is allocated once the steps start.
+    eng = z.Engine(device=local_rank)
     if regex_inputs is not None:
-        packed = engines[0].pack_with_regex(regex_inputs)           # registers the DFAs of the part list
-        for e in engines[1:]:                                        # same DFAs, same order -> same ids on every engine
-            e.pack_with_regex(regex_inputs[:1])
+        packed = eng.pack_with_regex(regex_inputs)           # registers the DFAs of the part list
     else:
         packed = A.PackedBatch(wl.emails)
     cb, keep, totals = device_batch(torch, packed, dev)
     n = packed.n
-    streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+    P = (packed.nh + packed.nb) if regex_inputs is not None else 0
+    eng.reserve(n, totals[0], S, P)
     # Result records.  One GPU: a slice per batch in flight.  N > 1: every timed step keeps its records (one slice per
     # step) and the ranks exchange them with ONE all-gather at the end of the timed region — SURVEY §8(e): "one exchange
     # step at the end".  (Measured alternatives on this box, forced through RCCL at N = 1: an all-gather inside every
@@ -172,18 +193,17 @@ def main():
         w[:, 0:8].copy_(r[:, 0:8])
         w[:, 8:72].copy_(r[:, 32:96])
         dist.all_gather_into_tensor(gathered_all, wit_local)
-    eng = engines[0]
-    stream_h = [streams[k].cuda_stream for k in range(S)]
     base_ptr = results_all.data_ptr()
     counter = [0]
 
     def step():
+        # slot i % S (the engine takes its slots round-robin) on that slot's own stream; record slice i % n_slices
         i = counter[0]
         counter[0] += 1
-        k = i % S
-        engines[k].verify_batch_device(cb, totals[0], totals[1], totals[2], base_ptr + (i % n_slices) * rec_bytes, stream_h[k])
+        eng.verify_batch_device(cb, totals[0], totals[1], totals[2], base_ptr + (i % n_slices) * rec_bytes, 0)
 
     def fence():
+        eng.sync()
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -192,6 +212,7 @@ def main():
     for _ in range(args.warmup):
         step()
     if use_dist:
+        eng.sync()
         torch.cuda.synchronize()
         exchange()                                    # untimed: first use of the copy kernels and of the communicator's all-gather
     fence()
@@ -199,7 +220,8 @@ def main():
     for _ in range(args.steps):
         step()
     if use_dist:
-        torch.cuda.synchronize()                      # every batch of this rank is done
+        eng.sync()                                    # every batch of this rank is done
+        torch.cuda.synchronize()
         exchange()
     fence()
     dt = time.perf_counter() - t0
@@ -210,7 +232,8 @@ def main():
 
     # ---- correctness of what was timed (outside the timed region)
     nocheck = os.environ.get("ZKE_BENCH_NOCHECK") == "1"       # kernel-ablation experiments only: results are not valid
-    written = sorted({i % n_slices for i in range(counter[0])})
+    first_timed = args.warmup
+    written = sorted({i % n_slices for i in range(first_timed, counter[0])})
     for sl in ([] if nocheck else sorted(set(written[:S]) | set(written[-2:]))):
         rec = results_all[sl * rec_bytes:(sl + 1) * rec_bytes].cpu().numpy().view(A.RESULT_DTYPE)
         n_ok = int((rec["status"] == 0).sum())
@@ -225,35 +248,57 @@ def main():
         mine = gathered_all[rank * g_steps * wit_bytes:(rank + 1) * g_steps * wit_bytes]
         assert bool((mine == D.witness_tensor(results_all[:g_steps * rec_bytes])).all().item())
 
-    # ---- per-kernel device time, HIP events on the launch stream (second pass, same steps)
-    # (one batch at a time on engine 0, so a launch's duration is not stretched by its neighbours)
+    # ---- per-kernel device time, HIP events on the stream each kernel is launched on
+    # (a) IN FLIGHT: the timed region's own mode — S batches in flight, events recorded between the kernels of every
+    #     batch, read from each slot once everything has drained (the last batch of each slot).  Not inside the timed
+    #     region itself: the event records cost a little, and `value` must not pay for its own instrumentation.
+    # (b) ALONE: one batch at a time (--alone-steps), what a kernel takes when nothing else shares the chip.
+    def avg_timings(rows):
+        return {k: sum(r[k] for r in rows) / len(rows) for k in rows[0]} if rows else None
+
     eng.set_timing(True)
-    acc = {}
-    tsteps = min(args.steps, 50)
-    for _ in range(tsteps):
-        eng.verify_batch_device(cb, totals[0], totals[1], totals[2], base_ptr, stream_h[0])
-        torch.cuda.synchronize()
-        tm = eng.timings()
-        for k, v in tm.items():
-            acc[k] = acc.get(k, 0.0) + v
+    for _ in range(max(S, min(args.steps, 2 * S))):
+        step()
+    eng.sync()
+    torch.cuda.synchronize()
+    kern_flight = avg_timings([eng.slot_timings(k) for k in range(S)])
+    kern_alone = None
+    if args.alone_steps > 0:
+        rows = []
+        for _ in range(args.alone_steps):
+            step()
+            eng.sync()
+            rows.append(eng.timings())
+        kern_alone = avg_timings(rows)
     eng.set_timing(False)
-    kern = {k: v / tsteps for k, v in acc.items()}
 
     emails_per_s = world * n * args.steps / dt
     # SHA-256 launch: algorithmic bytes = every byte hashed once + 32 B per digest
     hashed = wl.body_bytes + sum(len(it["canon_header"]) for it in wl.inter) + \
         sum(len(e.from_domain.encode()) + len(e.public_key.key) for e in wl.emails)
     sha_bytes = hashed + 32 * 4 * n
-    sha_s = kern["sha_us"] * 1e-6
+    sha_s = kern_flight["sha_us"] * 1e-6
     # HBM traffic of that launch from the PMC counters (rocprofv3 --pmc passes, committed under profiles/)
-    traffic = None
-    pmc_file = os.path.join(ROOT, "profiles", "r01_c2_sha_pmc.json")
-    if args.workload == "c2" and not args.batch and os.path.exists(pmc_file):
-        traffic = int(json.load(open(pmc_file))["hbm_bytes_per_launch"])
+    traffic, traffic_src = None, None
+    for pmc_name in ("r02_c2_sha_pmc.json", "r01_c2_sha_pmc.json"):
+        pmc_file = os.path.join(ROOT, "profiles", pmc_name)
+        if args.workload == "c2" and not args.batch and os.path.exists(pmc_file):
+            traffic, traffic_src = int(json.load(open(pmc_file))["hbm_bytes_per_launch"]), "profiles/" + pmc_name
+            break
+    gbps_of = (lambda us: round(sha_bytes / (us * 1e-6) / 1e9, 3) if us and us > 0 else None)
+    step_s = dt / args.steps
     roof = {
-        "bound": "hbm", "kernel": "sha256_pair_kernel<128>" if (4 * ((n + 63) // 64)) <= 512 else "sha256_batch_kernel<128>", "achieved": round(sha_bytes / sha_s / 1e9, 3) if sha_s > 0 else None,
-        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(sha_bytes / sha_s / 1e9 / HBM_PEAK_GBS, 5) if sha_s > 0 else None,
-        "traffic": traffic, "bytes_per_launch": sha_bytes, "launch_us": round(kern["sha_us"], 2),
+        "bound": "hbm", "kernel": "sha256_pair_kernel<128>" if (4 * ((n + 63) // 64)) <= 512 else "sha256_batch_kernel<128>",
+        "mode": f"{S} batches in flight (the timed region's mode): average duration of one launch, HIP events on its slot's stream",
+        "achieved": gbps_of(kern_flight["sha_us"]), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(sha_bytes / sha_s / 1e9 / HBM_PEAK_GBS, 5) if sha_s > 0 else None,
+        "traffic": traffic, "traffic_source": traffic_src, "bytes_per_launch": sha_bytes, "launch_us": round(kern_flight["sha_us"], 2),
+        # the same launch when its batch has the chip to itself, and the rate at which the timed region as a whole hashed
+        "alone": {"launch_us": round(kern_alone["sha_us"], 2), "achieved": gbps_of(kern_alone["sha_us"]),
+                  "frac": round(gbps_of(kern_alone["sha_us"]) / HBM_PEAK_GBS, 5)} if kern_alone else None,
+        "aggregate": {"bytes_per_step": sha_bytes, "ms_per_step": round(step_s * 1e3, 4),
+                      "achieved": round(sha_bytes / step_s / 1e9, 3), "frac": round(sha_bytes / step_s / 1e9 / HBM_PEAK_GBS, 5),
+                      "note": "hashed bytes of one step / ms_per_step of the timed region: S launches overlap"},
         "note": "SHA-256 on CDNA4 is integer-VALU bound: the compression alone sustains 1.82 TB/s on this chip "
                 "(profiles/r01_ubench_sha_alu.txt: ~1400 VALU per 64-byte block at ~3.9 cycles each), and a 1024-message launch is "
                 "bounded by the 65-block dependency chain of one message (split over two waves: schedule / rounds); see DESIGN.md §3",
@@ -267,7 +312,7 @@ def main():
         blob = torch.randint(0, 256, (nm * ml + 64,), dtype=torch.uint8, device=dev)
         off = (torch.arange(nm + 1, dtype=torch.int64, device=dev) * ml)
         dig = torch.zeros(nm * 32, dtype=torch.uint8, device=dev)
-        cur = streams[0]          # a real (non-null) HIP stream: the engine launches on the handle it is given
+        cur = torch.cuda.Stream(device=dev)          # a real (non-null) HIP stream: the engine launches on the handle it is given
         torch.cuda.synchronize()
         lib = eng.lib
         for _ in range(2):
@@ -299,7 +344,8 @@ def main():
                    "emails_per_step_per_gpu": n, "body_bytes": cfg["body_len"], "rsa_bits": cfg.get("rsa_bits", 0), "algo": cfg.get("algo", "rsa-sha256"),
                    "inputs": "HBM-resident raw e-mails", "batches_in_flight": S, "collective": "one RCCL all_gather of every step's 72-B witnesses (status + output hashes of each e-mail) at the end of the timed region" if use_dist else "none"},
         "roofline": roof,
-        "kernels_us": {k: round(v, 2) for k, v in kern.items()},
+        "kernels_us_in_flight": {k: round(v, 2) for k, v in kern_flight.items()},
+        "kernels_us_alone": {k: round(v, 2) for k, v in kern_alone.items()} if kern_alone else None,
         "sha256_saturated": sha_sat,
         "workload_gen_s": round(gen_s, 2),
     }

@@ -205,6 +205,15 @@ int zke_engine_create(const zke_options* opt, zke_engine** out);
 void zke_engine_destroy(zke_engine* e);
 const char* zke_last_error(const zke_engine* e);
 
+/* One engine per GPU.  An engine owns `slots` submission slots — a stream and a private workspace each — so that many
+ * batches can be in flight at once; what batches share (the per-key Montgomery constants of the RSA kernels, the
+ * registered DFA tables, kernel attributes) exists once per engine.  zke_engine_create makes one slot.
+ * zke_engine_reserve(e, max_n, max_raw_total, slots, max_regex_parts) raises the slot count to `slots` (1..64) and sizes
+ * every slot's workspace for batches of up to max_n e-mails / max_raw_total raw bytes (max_regex_parts > 0: the
+ * verify_email_with_regex buffers too), so that no allocation happens in the submit path afterwards.  A larger batch
+ * still works: its slot grows (one synchronising reallocation). */
+int zke_engine_reserve(zke_engine* e, uint32_t max_n, uint64_t max_raw_total, uint32_t slots, uint32_t max_regex_parts);
+
 /* Parse one regex-automata 0.4 dense-DFA pair once (replaces the per-email
  * dense::DFA::from_bytes of core/src/regex.rs:32-33), validate it and stage a repacked
  * transition table on the device.  Accepts unaligned input, so the align_slice shim
@@ -218,21 +227,47 @@ int zke_verify_batch(zke_engine* e, const zke_batch* in, zke_result* out, zke_de
 
 /* Device-resident batch: every pointer in `in` and `out_dev` is device memory;
  * `raw_total`, `domain_total`, `key_total` are the blob sizes (the CSR tails), which the
- * host needs for workspace sizing without a device read.  Enqueues on `stream`
- * (a hipStream_t, NULL = the engine's own stream) and returns without synchronising. */
+ * host needs for workspace sizing without a device read.  Takes the engine's next submission slot (round-robin),
+ * enqueues on `stream` (a hipStream_t; NULL = that slot's own stream) and returns without synchronising: with S slots
+ * reserved, S consecutive calls run concurrently.  A slot is reused only behind its previous batch (stream order, or an
+ * event wait when the caller's stream changed).  zke_engine_sync waits for every slot. */
 int zke_verify_batch_device(zke_engine* e, const zke_batch* in, uint64_t raw_total,
                             uint64_t domain_total, uint64_t key_total,
                             zke_result* out_dev, void* stream);
 int zke_engine_sync(zke_engine* e);
-int zke_get_timings(zke_engine* e, zke_timings* t);
+int zke_get_timings(zke_engine* e, zke_timings* t);                          /* the slot of the most recent batch */
+int zke_get_slot_timings(zke_engine* e, uint32_t slot, zke_timings* t);     /* the last batch that ran in `slot` */
 /* Enable per-kernel HIP-event timing (adds event records between kernels). */
 int zke_set_timing(zke_engine* e, int enabled);
 
-/* Single-email wrappers over a batch of one (config 1 / API-shape parity). */
+/* Single-email wrappers over a batch of one (config 1 / API-shape parity): the two functions of the reference,
+ *     verify_email(&Email)                      core/src/circuits.rs:9
+ *     verify_email_with_regex(&EmailWithRegex)  core/src/circuits.rs:31
+ * with the struct fields spelled out as pointers and sizes.  `external_input_null` != 0: some ExternalInput.value is
+ * None (circuits.rs:24 panics after the DKIM assert and before any regex work; the status order is the reference's). */
 int zke_verify_email(zke_engine* e, const uint8_t* raw, size_t raw_len,
                      const char* from_domain, size_t domain_len,
                      const uint8_t* key, size_t key_len, uint32_t key_type,
-                     zke_result* out);
+                     uint32_t external_input_null, zke_result* out);
+
+/* One CompiledRegex of RegexInfo.header_parts / body_parts (core/src/structs.rs:16-35). */
+typedef struct zke_regex_part {
+  const uint8_t* fwd; size_t fwd_len;        /* verify_re.fwd: regex-automata dense DFA, little-endian, padding stripped */
+  const uint8_t* bwd; size_t bwd_len;        /* verify_re.bwd */
+  uint32_t n_captures;                       /* captures: Some(v) -> v.len(); None -> 0 (core/src/regex.rs:41 skips the check) */
+  const uint8_t* const* captures;            /* [n_captures] UTF-8 bytes, no terminator needed */
+  const size_t* capture_lens;                /* [n_captures] */
+} zke_regex_part;
+
+/* Registers the DFA pairs it has not seen before (zke_dfa_register returns the old id for an equal pair), so calling
+ * this per e-mail with the same regex_config parses every table once, not once per e-mail as core/src/regex.rs:32-33. */
+int zke_verify_email_with_regex(zke_engine* e, const uint8_t* raw, size_t raw_len,
+                                const char* from_domain, size_t domain_len,
+                                const uint8_t* key, size_t key_len, uint32_t key_type,
+                                uint32_t external_input_null,
+                                const zke_regex_part* header_parts, uint32_t n_header_parts,
+                                const zke_regex_part* body_parts, uint32_t n_body_parts,
+                                zke_result* out);
 
 /* Building blocks, exported for parity tests and micro-benchmarks.  Host pointers. */
 /* n messages msg_blob[off[i]..off[i+1]) -> digests[32*i..]           (core/src/crypto.rs:3-7) */

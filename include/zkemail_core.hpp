@@ -8,7 +8,6 @@
 // to std::terminate.
 #pragma once
 #include <cstdint>
-#include <map>
 #include <memory>
 #include <optional>
 #include <stdexcept>
@@ -99,51 +98,46 @@ class Engine {
   }
 
  private:
-  uint32_t dfa_id(const DFA& d) {
-    auto key = std::make_pair(d.fwd, d.bwd);
-    auto it = ids_.find(key);
-    if (it != ids_.end()) return it->second;
-    uint32_t id = 0;
-    if (int r = zke_dfa_register(e_, d.fwd.data(), d.fwd.size(), d.bwd.data(), d.bwd.size(), &id))
-      throw EngineError(std::string("zke_dfa_register: ") + zke_last_error(e_));
-    ids_.emplace(std::move(key), id);
-    return id;
-  }
-  static uint8_t key_type_code(const std::string& t) {
+  static uint32_t key_type_code(const std::string& t) {
     return t == "rsa" ? ZKE_KEY_RSA : (t == "ed25519" ? ZKE_KEY_ED25519 : ZKE_KEY_OTHER);
   }
+  // One e-mail through the single-e-mail entry points of the C-ABI (zke_verify_email / zke_verify_email_with_regex).
   zke_result run(const Email& em, const RegexInfo* ri) {
-    const uint64_t ro[2] = {0, em.raw_email.size()}, dofs[2] = {0, em.from_domain.size()}, ko[2] = {0, em.public_key.key.size()};
-    const uint8_t kt = key_type_code(em.public_key.key_type);
-    uint8_t ext = 0;
+    uint32_t ext = 0;
     for (const auto& x : em.external_inputs) if (!x.value) ext = 1;                      // circuits.rs:24
-    static const uint8_t dummy = 0;
-    zke_batch b{};
-    b.n = 1;
-    b.raw_blob = em.raw_email.empty() ? &dummy : em.raw_email.data(); b.raw_off = ro;
-    b.domain_blob = em.from_domain.empty() ? &dummy : reinterpret_cast<const uint8_t*>(em.from_domain.data()); b.domain_off = dofs;
-    b.key_blob = em.public_key.key.empty() ? &dummy : em.public_key.key.data(); b.key_off = ko;
-    b.key_type = &kt; b.ext_null = &ext;
-    std::vector<uint32_t> hids, bids, cap_off{0}, str_off{0};
-    std::vector<uint8_t> blob;
-    if (ri) {
-      b.with_regex = 1;
+    const uint32_t kt = key_type_code(em.public_key.key_type);
+    zke_result r{};
+    int rc;
+    if (!ri) {
+      rc = zke_verify_email(e_, em.raw_email.data(), em.raw_email.size(), em.from_domain.data(), em.from_domain.size(),
+                            em.public_key.key.data(), em.public_key.key.size(), kt, ext, &r);
+    } else {
+      // RegexInfo -> two zke_regex_part lists; the pointer tables live until the call returns
+      std::vector<zke_regex_part> hp, bp;
+      std::vector<std::vector<const uint8_t*>> ptrs;
+      std::vector<std::vector<size_t>> lens;
+      size_t total = 0;
+      for (const auto* parts : {&ri->header_parts, &ri->body_parts}) if (*parts) total += (*parts)->size();
+      ptrs.reserve(total); lens.reserve(total);
       for (const auto* parts : {&ri->header_parts, &ri->body_parts}) {
         if (!*parts) continue;
         for (const auto& p : **parts) {
-          (parts == &ri->header_parts ? hids : bids).push_back(dfa_id(p.verify_re));
+          ptrs.emplace_back(); lens.emplace_back();
           if (p.captures)
-            for (const auto& s : *p.captures) { blob.insert(blob.end(), s.begin(), s.end()); str_off.push_back((uint32_t)blob.size()); }
-          cap_off.push_back((uint32_t)str_off.size() - 1);
+            for (const auto& s : *p.captures) { ptrs.back().push_back(reinterpret_cast<const uint8_t*>(s.data())); lens.back().push_back(s.size()); }
+          zke_regex_part q{};
+          q.fwd = p.verify_re.fwd.data(); q.fwd_len = p.verify_re.fwd.size();
+          q.bwd = p.verify_re.bwd.data(); q.bwd_len = p.verify_re.bwd.size();
+          q.n_captures = (uint32_t)ptrs.back().size();
+          q.captures = ptrs.back().data(); q.capture_lens = lens.back().data();
+          (parts == &ri->header_parts ? hp : bp).push_back(q);
         }
       }
-      if (blob.empty()) blob.push_back(0);
-      b.n_header_parts = (uint32_t)hids.size(); b.n_body_parts = (uint32_t)bids.size();
-      b.header_part_ids = hids.data(); b.body_part_ids = bids.data();
-      b.cap_off = cap_off.data(); b.cap_str_off = str_off.data(); b.cap_blob = blob.data();
+      rc = zke_verify_email_with_regex(e_, em.raw_email.data(), em.raw_email.size(), em.from_domain.data(), em.from_domain.size(),
+                                       em.public_key.key.data(), em.public_key.key.size(), kt, ext, hp.data(), (uint32_t)hp.size(),
+                                       bp.data(), (uint32_t)bp.size(), &r);
     }
-    zke_result r{};
-    if (int rc = zke_verify_batch(e_, &b, &r, nullptr)) throw EngineError(std::string("zke_verify_batch: ") + zke_last_error(e_) + " (" + std::to_string(rc) + ")");
+    if (rc) throw EngineError(std::string("zke_verify_email: ") + zke_last_error(e_) + " (" + std::to_string(rc) + ")");
     return r;
   }
   static EmailVerifierOutput output(const Email& em, const zke_result& r) {
@@ -154,7 +148,6 @@ class Engine {
     return o;
   }
   zke_engine* e_ = nullptr;
-  std::map<std::pair<std::vector<uint8_t>, std::vector<uint8_t>>, uint32_t> ids_;
 };
 
 inline Engine& default_engine() {

@@ -13,9 +13,9 @@ from typing import List, Optional
 import numpy as np
 
 from zkemail_rs_amd import _abi as A
-from zkemail_rs_amd import synth
+import synth
 from zkemail_rs_amd._abi import Email, PublicKey
-from zkemail_rs_amd.synth import SignSpec, sign_email
+from synth import SignSpec, sign_email
 
 
 @dataclass
@@ -48,7 +48,7 @@ def ED():
 
 def _not_a_point() -> bytes:
     """32 bytes VerifyingKey::from_bytes rejects (decided by the Python-integer decompression)."""
-    from zkemail_rs_amd import ed25519_ref as ed
+    import ed25519_ref as ed
     rng = np.random.default_rng(99)
     while True:
         k = rng.integers(0, 256, 32, dtype=np.uint8).tobytes()
@@ -65,7 +65,7 @@ def _replace_sig(raw: bytes, new_sig: bytes) -> bytes:
 
 def _ed25519_cases() -> List[Case]:
     """k=ed25519 / a=ed25519-sha256 (RFC 8463): Ed25519 over the SHA-256 header hash."""
-    from zkemail_rs_amd import ed25519_ref as ed
+    import ed25519_ref as ed
     cs: List[Case] = []
     e0, e1 = ED()[0], ED()[1]
     kw = dict(key_type="ed25519")

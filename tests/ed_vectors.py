@@ -3,7 +3,7 @@ single-bit corruptions, and the edge cases that separate dalek's verify_strict f
 come from zkemail_rs_amd.ed25519_ref (Python ints), never from the oracle or the device."""
 import numpy as np
 
-from zkemail_rs_amd import ed25519_ref as ed
+import ed25519_ref as ed
 
 
 def _enc(pt):

@@ -16,12 +16,18 @@ import re
 from dataclasses import dataclass, replace
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import sys
+
 import numpy as np
 
-from ._abi import Email, PublicKey
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if _ROOT not in sys.path:           # run as a script (make_workload_parallel's workers): the repo root is not on the path yet
+    sys.path.insert(0, _ROOT)
+import zkemail_rs_amd  # noqa: F401,E402  (import shim of the dotted package directory)
+from zkemail_rs_amd._abi import Email, PublicKey  # noqa: E402
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-KEYS_JSON = os.path.join(os.path.dirname(_HERE), "tests", "golden", "keys.json")
+KEYS_JSON = os.path.join(_HERE, "golden", "keys.json")
 
 SHA256_DIGESTINFO = bytes.fromhex("3031300d060960864801650304020105000420")
 SHA1_DIGESTINFO = bytes.fromhex("3021300906052b0e03021a05000414")
@@ -69,7 +75,7 @@ class EdKey:
 
 def ed_keys(count: int, seed: int = 25519) -> List["EdKey"]:
     """Deterministic Ed25519 keys (seeds from a seeded generator; public keys by ed25519_ref, RFC 8032 §5.1.5)."""
-    from . import ed25519_ref as ed
+    import ed25519_ref as ed
     rng = np.random.default_rng(seed)
     out = []
     for i in range(count):
@@ -238,7 +244,7 @@ def sign_email(headers: List[Tuple[bytes, bytes]], body: bytes, key: RsaKey, spe
     pre += hc(spec.sig_header_name, sig_value_unsigned)[:-2]
     hh = H(pre).digest()
     if isinstance(key, EdKey):         # RFC 8463 §3: the Ed25519 message is the SHA-256 header hash
-        from . import ed25519_ref as ed
+        import ed25519_ref as ed
         em, sig = b"", ed.sign(key.seed, hh)
     else:
         em = emsa_pkcs1_v15_sha256(hh, key.k)
@@ -366,6 +372,51 @@ def make_workload(name: str, n: int, body_len: int, rsa_bits: int = 2048, n_keys
     return Workload(name, emails, inter, bsum, rsum)
 
 
+def make_workload_parallel(name: str, n: int, body_len: int, seed: int = 2, workers: int = 0, chunk: int = 512, **kw) -> Workload:
+    """make_workload in `chunk`-e-mail pieces, each in a fresh interpreter (`python synth.py --gen ...`: child
+    processes that never touch the GPU, safe to start after this process has initialised it).  Deterministic for
+    given (n, chunk, seed): piece j is make_workload(seed = seed * 4099 + j).  Python-integer RSA signing is ~9 ms
+    per e-mail, so the full-size test batches would take minutes on one core."""
+    import pickle
+    import subprocess
+    import sys
+    import tempfile
+    workers = workers or min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    jobs = [dict(name=name, n=min(chunk, n - start), body_len=body_len, seed=seed * 4099 + j, **kw)
+            for j, start in enumerate(range(0, n, chunk))]
+    parts: List[Optional[Workload]] = [None] * len(jobs)
+    if workers <= 1 or len(jobs) == 1:
+        parts = [make_workload(**j) for j in jobs]
+    else:
+        with tempfile.TemporaryDirectory() as td:
+            running, nxt = {}, 0
+            while nxt < len(jobs) or running:
+                while nxt < len(jobs) and len(running) < workers:
+                    out = os.path.join(td, f"{nxt}.pkl")
+                    running[nxt] = (subprocess.Popen([sys.executable, os.path.abspath(__file__), "--gen", json.dumps(jobs[nxt]), out]), out)
+                    nxt += 1
+                for j in list(running):
+                    proc, out = running[j]
+                    if proc.poll() is None:
+                        continue
+                    if proc.returncode != 0:
+                        raise RuntimeError(f"workload piece {j} failed ({proc.returncode})")
+                    with open(out, "rb") as f:
+                        parts[j] = pickle.load(f)
+                    os.remove(out)
+                    del running[j]
+                if running:
+                    import time
+                    time.sleep(0.05)
+    out_wl = Workload(name, [], [], 0, 0)
+    for p in parts:
+        out_wl.emails += p.emails
+        out_wl.inter += p.inter
+        out_wl.body_bytes += p.body_bytes
+        out_wl.raw_bytes += p.raw_bytes
+    return out_wl
+
+
 CONFIGS = {
     # BASELINE.json configs[0..4]
     "c1": dict(n=1, body_len=300, rsa_bits=2048, n_keys=1, seed=1, hdr_pad=0),
@@ -415,8 +466,8 @@ def make_regex_workload(name: str, n: int, body_len: int, rsa_bits: int = 2048, 
                         n_header_parts: int = 2, n_body_parts: int = 0, qp_frac: float = 0.0, fail_frac: float = 0.0):
     """EmailWithRegex batch sharing one part list (BASELINE configs[2] / configs[4] shape).  Returns
     (inputs, workload, expect) where expect[i] is None for a passing e-mail or 'header'/'body'."""
-    from . import regex_compile as rc
-    from ._abi import CompiledRegex, EmailWithRegex, RegexInfo
+    from zkemail_rs_amd import regex_compile as rc
+    from zkemail_rs_amd._abi import CompiledRegex, EmailWithRegex, RegexInfo
     rng = np.random.default_rng(seed)
     keys = keys_of(rsa_bits, n_keys)
     hp = HEADER_PATTERNS[:n_header_parts]
@@ -462,3 +513,14 @@ def make_regex_workload(name: str, n: int, body_len: int, rsa_bits: int = 2048, 
         emails.append(em); inter.append(it); expect.append(fail)
     wl = Workload(name, emails, inter, sum(x["hashed_body_len"] for x in inter), sum(len(e.raw_email) for e in emails))
     return inputs, wl, expect
+
+
+if __name__ == "__main__":         # worker of make_workload_parallel: python synth.py --gen '<json kwargs>' <out.pkl>
+    import pickle
+    import sys
+    if len(sys.argv) == 4 and sys.argv[1] == "--gen":
+        sys.path.insert(0, _HERE)
+        import synth as _synth          # pickle must name the classes by this module, not by __main__
+        wl_ = _synth.make_workload(**json.loads(sys.argv[2]))
+        with open(sys.argv[3], "wb") as f_:
+            pickle.dump(wl_, f_, protocol=pickle.HIGHEST_PROTOCOL)

@@ -67,3 +67,29 @@ def test_packed_batch_layout():
     assert list(p.key_type) == [A.KEY_RSA, A.KEY_ED25519] and list(p.ext_null) == [0, 1]
     assert list(p.cap_off) == [0, 1, 3, 3, 3, 4, 5] and list(p.cap_str_off) == [0, 1, 2, 4, 5, 6]
     assert p.c.n == 2 and p.c.with_regex == 1 and p.c.n_header_parts == 1 and p.c.n_body_parts == 2
+
+
+def test_null_arguments_are_refused_not_dereferenced():
+    """Every entry point checks its engine handle and pointers before anything else (no GPU needed: the checks come
+    first).  zke_verify_batch_device used to write through a null engine before looking at it."""
+    lib = engine.load_library()
+    vp = C.c_void_p
+    b = A.zke_batch()
+    out = np.zeros(1, dtype=A.RESULT_DTYPE)
+    E_ARG = -1
+    assert lib.zke_verify_batch_device(None, C.byref(b), 0, 0, 0, out.ctypes.data, None) == E_ARG
+    assert lib.zke_verify_batch(None, C.byref(b), out.ctypes.data, None) == E_ARG
+    assert lib.zke_verify_email(None, None, 0, None, 0, None, 0, 0, 0, out.ctypes.data) == E_ARG
+    assert lib.zke_verify_email_with_regex(None, None, 0, None, 0, None, 0, 0, 0, None, 0, None, 0, out.ctypes.data) == E_ARG
+    assert lib.zke_engine_reserve(None, 1, 1, 1, 0) == E_ARG
+    assert lib.zke_engine_sync(None) == E_ARG
+    assert lib.zke_set_timing(None, 1) == E_ARG
+    t = A.zke_timings()
+    assert lib.zke_get_timings(None, C.byref(t)) == E_ARG and lib.zke_get_slot_timings(None, 0, C.byref(t)) == E_ARG
+    u = C.c_uint32()
+    assert lib.zke_dfa_register(None, None, 0, None, 0, C.byref(u)) == E_ARG
+    assert lib.zke_sha256_batch(None, None, None, 0, None) == E_ARG
+    assert lib.zke_rsa_modexp_batch(None, None, None, None, 256, 0, None, None) == E_ARG
+    assert lib.zke_ed25519_verify_batch(None, None, None, 32, None, 0, None) == E_ARG
+    lib.zke_engine_destroy(None)          # a no-op, as free(NULL)
+    assert lib.zke_last_error(None) == b"null engine"

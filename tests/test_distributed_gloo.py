@@ -17,7 +17,8 @@ import os, sys
 sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
 import numpy as np, torch, torch.distributed as dist
 import oracle_lib
-from zkemail_rs_amd import _abi as A, synth, distributed as D
+from zkemail_rs_amd import _abi as A, distributed as D
+import synth
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 wl = synth.make_workload("dist", 37, 6000, seed=77, ragged=True, invalid_frac=0.2)

@@ -5,7 +5,7 @@ import hashlib
 import numpy as np
 import pytest
 
-from zkemail_rs_amd import synth
+import synth
 
 pytestmark = pytest.mark.gpu
 
@@ -90,7 +90,7 @@ def test_ed25519_verify_batch_parity(engine, oracle):
 
 def test_ed25519_sha1_sized_message(engine, oracle):
     """a 20-byte message (an rsa-sha1 style header hash) goes through the same one-block SHA-512 path"""
-    from zkemail_rs_amd import ed25519_ref as ed
+    import ed25519_ref as ed
     rng = np.random.default_rng(3)
     keys, msgs, sigs = [], [], []
     for _ in range(70):                         # more than one wave

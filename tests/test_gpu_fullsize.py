@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from zkemail_rs_amd import _abi as A
-from zkemail_rs_amd import synth
+import synth
 
 pytestmark = pytest.mark.gpu
 
@@ -71,11 +71,65 @@ def test_config5_shard(engine):
     assert (got["rsa_bits"] == 4096).all() and (got["regex_part"] == 3).all() and (got["match_count"] == 1).all()
 
 
-def test_config4_slice(engine):
-    """64 KiB bodies (config 4's shape; a 512-e-mail slice of a GPU's 8 192): 1 025 SHA-256 blocks per body."""
-    wl = synth.make_workload("c4", 512, 65536, rsa_bits=2048, n_keys=16, seed=4)
-    assert wl.body_bytes == 512 * 65536
-    check_workload(engine, wl, A.PackedBatch(wl.emails))
+def records_equal(got, exp, what):
+    for f in A.RESULT_DTYPE.names:
+        if f != "reserved":
+            bad = np.nonzero((np.asarray(got[f]) != np.asarray(exp[f])).reshape(len(got), -1).any(axis=1))[0]
+            assert len(bad) == 0, f"{what}: field {f} differs from the oracle at records {bad[:8]}"
+
+
+def test_config4_full_shard(engine, oracle):
+    """configs[3] at its real per-GPU size: 8 192 e-mails x 64 KiB bodies = one GPU's shard of the 65 536-e-mail batch
+    (0.5 GiB of raw e-mail in one zke_verify_batch call, 1 GiB of scratch, slot offsets up to 2^30, 1 025 SHA-256
+    blocks per body, the lane-group RSA kernel).  Every record: status, both hashes and both lengths against the
+    Python signer's own values, and the whole 192-byte record against the oracle."""
+    wl = synth.make_workload_parallel("c4", 8192, 65536, rsa_bits=2048, n_keys=16, seed=4)
+    assert len(wl.emails) == 8192 and wl.body_bytes == 8192 * 65536
+    for it in wl.inter:
+        it.pop("canon_body", None)                      # 0.5 GiB the checks below do not need
+    packed = A.PackedBatch(wl.emails)
+    assert int(packed.raw_off[-1]) > (1 << 29)
+    got = check_workload(engine, wl, packed)
+    assert (got["rsa_bits"] == 2048).all() and (got["sig_index"] == 0).all()
+    pk = {bytes(e.public_key.key): hashlib.sha256(e.public_key.key).digest() for e in wl.emails[:16]}
+    assert all(bytes(got[i]["public_key_hash"]) == pk[bytes(wl.emails[i].public_key.key)] for i in range(0, 8192, 61))
+    records_equal(got, oracle.verify_batch(packed, threads=16), "configs[3] shard")
+
+
+def test_config4_ragged_and_invalid_mix(engine, oracle):
+    """SURVEY §8(d)'s two variants at the shard's e-mail count: body lengths log-uniform in 3 B ... 64 KiB (divergence
+    between the lanes of a SHA-256 wave and between front-end waves) and a 1 % invalid mix (one flipped body or
+    header bit: the status must name the reference's failing compare, the untouched hash must still be the signer's)."""
+    wl = synth.make_workload_parallel("c4-ragged", 8192, 65536, rsa_bits=2048, n_keys=16, seed=44, ragged=True, invalid_frac=0.01)
+    lens = np.array([it["hashed_body_len"] for it in wl.inter])
+    assert lens.min() < 64 and lens.max() > 40000
+    for it in wl.inter:
+        it.pop("canon_body", None)
+    packed = A.PackedBatch(wl.emails)
+    got = engine.verify_batch(packed)
+    n_bad = 0
+    for i, it in enumerate(wl.inter):
+        r = got[i]
+        c = it["corrupt"]
+        # a flipped bit in a 3-byte body can hit the CRLF; the oracle comparison below covers those records
+        if c is None:
+            assert int(r["status"]) == A.ZKE_OK, (i, int(r["status"]), int(r["detail"]))
+            assert bytes(r["body_hash"]) == it["body_hash"] and bytes(r["header_hash"]) == it["header_hash"], i
+            assert int(r["canon_body_len"]) == it["hashed_body_len"] and int(r["canon_header_len"]) == len(it["canon_header"]), i
+        else:
+            n_bad += 1
+            assert int(r["status"]) == A.ZKE_DKIM_NOT_PASS, (i, c, int(r["status"]))
+            if c == "body":
+                assert int(r["detail"]) == A.D_BODY_HASH_MISMATCH and bytes(r["header_hash"]) == it["header_hash"], i
+                assert bytes(r["body_hash"]) != it["body_hash"], i
+            else:
+                assert int(r["detail"]) == A.D_SIG_MISMATCH and bytes(r["body_hash"]) == it["body_hash"], i
+                assert bytes(r["header_hash"]) != it["header_hash"], i
+            assert not any(r["from_domain_hash"]) and not any(r["public_key_hash"]), i      # no witness for a failed e-mail
+    assert 40 <= n_bad <= 130
+    records_equal(got, oracle.verify_batch(packed, threads=16), "ragged + 1 % invalid")
+    again = engine.verify_batch(packed)
+    assert again.tobytes() == got.tobytes()
 
 
 def test_config2_shape_ed25519(engine):

@@ -9,7 +9,7 @@ from test_gpu_verify import assert_records_equal
 from test_regex_dfa import HAYS, PATTERNS, rust_find_iter
 from zkemail_rs_amd import _abi as A
 from zkemail_rs_amd import regex_compile as rc
-from zkemail_rs_amd import synth
+import synth
 
 pytestmark = pytest.mark.gpu
 

@@ -9,8 +9,8 @@ import pytest
 
 import cases
 from zkemail_rs_amd import _abi as A
-from zkemail_rs_amd import synth
-from zkemail_rs_amd.synth import SignSpec
+import synth
+from synth import SignSpec
 
 pytestmark = pytest.mark.gpu
 
@@ -192,7 +192,7 @@ def test_lane_front_end_variant_parity(tmp_path):
         sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r})
         import oracle_lib, cases, test_gpu_verify as t, test_gpu_regex as tr
         import zkemail_rs_amd as z
-        from zkemail_rs_amd import synth
+        import synth
         eng, orc = z.Engine(), oracle_lib.load()
         t.test_case_corpus_parity(eng, orc)
         for seed in (99, 7):
@@ -299,7 +299,8 @@ def test_device_resident_entry_matches_host_entry():
         import numpy as np, torch
         torch.zeros(1, device="cuda")
         import bench, zkemail_rs_amd as z
-        from zkemail_rs_amd import _abi as A, synth
+        from zkemail_rs_amd import _abi as A
+        import synth
         from test_gpu_verify import assert_records_equal
         engine = z.Engine(0)
         dev = torch.device("cuda", 0)
@@ -325,6 +326,25 @@ def test_device_resident_entry_matches_host_entry():
                 torch.cuda.synchronize()
                 rec = out.cpu().numpy().view(A.RESULT_DTYPE)
                 assert_records_equal(rec, host, None, f"device mode rep {{rep}} regex={{with_regex}}")
+            # submission slots: 4 reserved, 12 batches in flight on the slots' own streams (stream = NULL), then 8 more
+            # alternating between two caller streams (a slot reused from another stream waits for its previous batch)
+            engine.reserve(packed.n, totals[0], 4, (packed.nh + packed.nb) if with_regex else 0)
+            outs = [torch.zeros(packed.n * 192, dtype=torch.uint8, device=dev) for _ in range(12)]
+            torch.cuda.synchronize()
+            for o in outs:
+                engine.verify_batch_device(cb, totals[0], totals[1], totals[2], o.data_ptr(), 0)
+            engine.sync()
+            for k, o in enumerate(outs):
+                assert_records_equal(o.cpu().numpy().view(A.RESULT_DTYPE), host, None, f"slot batch {{k}} regex={{with_regex}}")
+            sts = [torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()]
+            for o in outs:
+                o.zero_()
+            torch.cuda.synchronize()
+            for k, o in enumerate(outs[:9]):
+                engine.verify_batch_device(cb, totals[0], totals[1], totals[2], o.data_ptr(), sts[k % 3].cuda_stream)
+            engine.sync()
+            for k, o in enumerate(outs[:9]):
+                assert_records_equal(o.cpu().numpy().view(A.RESULT_DTYPE), host, None, f"caller-stream batch {{k}} regex={{with_regex}}")
         print("device entry ok")
     """)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from zkemail_rs_amd import synth
+import synth
 
 NIST = [
     (b"abc", "ba7816bf8f01cfea414140de5dae2223b00361a396177a9cb410ff61f20015ad"),

@@ -7,7 +7,7 @@ import pytest
 
 import cases
 from zkemail_rs_amd import _abi as A
-from zkemail_rs_amd import synth
+import synth
 
 CASES = cases.build_cases()
 

@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 import ed_vectors
-from zkemail_rs_amd import ed25519_ref as ed
+import ed25519_ref as ed
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ed25519.json")
 

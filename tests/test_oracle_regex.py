@@ -7,7 +7,7 @@ import pytest
 import cases
 from zkemail_rs_amd import _abi as A
 from zkemail_rs_amd import regex_compile as rc
-from zkemail_rs_amd import synth
+import synth
 
 
 def test_regex_workload_header_parts(oracle):

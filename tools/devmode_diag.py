@@ -5,7 +5,8 @@ sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
 import numpy as np, torch
 torch.zeros(1, device="cuda")
 import bench, zkemail_rs_amd as z
-from zkemail_rs_amd import _abi as A, synth
+from zkemail_rs_amd import _abi as A
+import synth
 from test_gpu_verify import assert_records_equal
 with_regex, reps = int(sys.argv[1]), int(sys.argv[2])
 engine = z.Engine(0)

@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
 import torch
 import zkemail_rs_amd as z
-from zkemail_rs_amd import _abi as A, synth
+from zkemail_rs_amd import _abi as A
+import synth
 import bench
 S, N = 20, 4000
 dev = torch.device("cuda", 0)

@@ -3,7 +3,9 @@ pipeline, D2H of the records.  Reported in DESIGN.md §5; never bench.py's `valu
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import zkemail_rs_amd as z
-from zkemail_rs_amd import _abi as A, synth
+from zkemail_rs_amd import _abi as A
+import zkemail_rs_amd  # noqa: F401  (import shim for the dotted package directory)
+import synth
 for name, cfg in (("c2", dict(n=1024, body_len=4096)), ("8192x4KB", dict(n=8192, body_len=4096)), ("1024x64KB", dict(n=1024, body_len=65536))):
     wl = synth.make_workload(name, seed=3, **cfg)
     packed = A.PackedBatch(wl.emails)

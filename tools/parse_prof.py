@@ -2,7 +2,8 @@ import os, sys, json
 sys.path.insert(0, "/root/repo")
 import numpy as np, torch
 import zkemail_rs_amd as z
-from zkemail_rs_amd import _abi as A, synth
+from zkemail_rs_amd import _abi as A
+import synth
 sys.path.insert(0, "/root/repo"); 
 import bench
 wl = synth.make_workload("c2", 1024, 4096, seed=1)

@@ -132,6 +132,14 @@ class zke_debug_out(C.Structure):
     ]
 
 
+class zke_regex_part(C.Structure):
+    """One CompiledRegex (core/src/structs.rs:24-27) as zke_verify_email_with_regex takes it."""
+    _fields_ = [
+        ("fwd", C.c_void_p), ("fwd_len", C.c_size_t), ("bwd", C.c_void_p), ("bwd_len", C.c_size_t),
+        ("n_captures", C.c_uint32), ("captures", C.POINTER(C.c_void_p)), ("capture_lens", C.POINTER(C.c_size_t)),
+    ]
+
+
 class zke_options(C.Structure):
     _fields_ = [("device", C.c_int32), ("reserved", C.c_uint32 * 7)]
 

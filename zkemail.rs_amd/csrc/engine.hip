@@ -51,6 +51,7 @@ struct RegisteredDfa {
   uint32_t idle = 0xFFFFFFFFu;   // forward automaton's idle state (dfa_idle_state)
   DevBuf blob;              // the repacked tables
   DevBuf dev;               // RegexDev image
+  std::vector<uint8_t> fwd_copy, bwd_copy;     // the registered bytes: zke_dfa_register gives an equal pair its old id
 };
 
 inline uint32_t e_k(uint32_t bits) { return (bits + 7) / 8; }
@@ -60,26 +61,40 @@ constexpr uint32_t SHA_PAIR_MAX_GROUPS = 512;      // launches of up to 32 768 m
 
 }  // namespace
 
+// One submission slot: a stream and a private workspace.  A batch runs in one slot from its first kernel to its
+// last; `slots` batches can be in flight on one engine (zke_engine_reserve).  What batches share lives in the engine:
+// the per-key Montgomery constants (one cache per device) and the registered DFA tables.
+struct Slot {
+  hipStream_t stream = nullptr;        // the slot's own stream: batches submitted with stream == NULL run here
+  hipStream_t last_stream = nullptr;   // stream of the slot's previous batch (nullptr: the slot has not been used)
+  hipEvent_t done = nullptr;           // recorded behind the slot's last batch; waited for when the stream changes
+  hipEvent_t ev[16]{};                 // per-kernel timing marks (zke_set_timing)
+  int timed_marks = 0;
+  bool timed_regex = false;
+  DevBuf meta, rsa_jobs, sha_jobs, rsa_ok, em_dbg, scratch_off, scratch, clean, meta2, scratch2, parts;
+  DevBuf lanews;   // LaneWs[n]: per-e-mail header table / tag records / tag values of the lane-per-e-mail front end
+  DevBuf pending;  // device counters: e-mails that need another signature round
+  DevBuf* all[13] = {&meta, &rsa_jobs, &sha_jobs, &rsa_ok, &em_dbg, &scratch_off, &scratch, &clean, &meta2, &scratch2, &parts, &lanews, &pending};
+};
+
 struct zke_engine {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;     // = slots[0]->stream: host-mode batches and the building-block entry points
   std::string err;
   bool timing = false;
   zke_timings last{};
-  hipEvent_t ev[16]{};
   hipEvent_t ev_h2d[4]{};
-  int timed_marks = 0;
-  bool timed_regex = false;
+  std::vector<Slot*> slots;         // at least one (zke_engine_create); more after zke_engine_reserve
+  uint32_t next_slot = 0;           // round-robin cursor of zke_verify_batch_device
+  uint32_t last_slot = 0;           // slot of the most recent batch (zke_get_timings)
   size_t dfa_lds_attr = 0;
   std::vector<uint32_t> host_hdr_ids, host_body_ids;
-  // device workspace
+  // host-mode staging of the inputs and results (zke_verify_batch)
   DevBuf in_raw, in_raw_off, in_dom, in_dom_off, in_key, in_key_off, in_ktype, in_extnull;
   DevBuf in_cap_off, in_cap_str_off, in_cap_blob;
-  DevBuf results, meta, rsa_jobs, sha_jobs, rsa_ok, em_dbg, scratch_off, scratch, clean, meta2, scratch2, parts;
+  DevBuf results;
   DevBuf misc;   // building-block entry points
-  DevBuf key_cache; // KeyCacheEntry[KEY_CACHE_SLOTS]: per-key Montgomery constants, kept across batches
-  DevBuf lanews;  // LaneWs[n]: per-e-mail header table / tag records / tag values of the front kernel
-  DevBuf pending; // device counter: e-mails that need another signature round
+  DevBuf key_cache; // KeyCacheEntry[KEY_CACHE_SLOTS]: per-key Montgomery constants, kept across batches, shared by the slots
   std::vector<RegisteredDfa*> dfas;
   int sha_tile = SHA_TILE;
   int dfa_wave = 1;                 // regex parts: one e-mail per wave with a chunk map (ZKE_DFA_WAVE=0: one e-mail per lane)
@@ -89,7 +104,6 @@ struct zke_engine {
   uint32_t rsa_quad_min = 2048;     // -1: batches of at least this many e-mails (ZKE_RSA_QUAD_MIN)
   uint32_t rsa_oct_min = 1024;      // ... for the eight-lane form of moduli above 2048 bits (ZKE_RSA_OCT_MIN)
   int sha_pair = -1;                // two-wave SHA-256 kernel: -1 by launch size, 0 never, 1 always (ZKE_SHA_PAIR)
-  bool front_attr_set = false;
   bool wave_parse = true;           // front end: one e-mail per wavefront (parse.hip.h); ZKE_LANE_PARSE=1 selects the
                                     // one-e-mail-per-lane variant (front.hip.h), see DESIGN.md §3
   uint32_t debug_skip_rsa = 0;      // ZKE_DEBUG_SKIP_RSA: ablation experiments (results are then meaningless)
@@ -111,27 +125,26 @@ int fail(zke_engine* e, int code, const char* what, hipError_t he = hipSuccess) 
 }
 #define HIPCHK(e, call) do { hipError_t _r = (call); if (_r != hipSuccess) return fail((e), ZKE_E_DEVICE, #call, _r); } while (0)
 
+// Kernel attributes are per device, so they belong to the engine (one engine = one device) and are set once at
+// creation — never lazily in the submit path, where a first use would land inside somebody's timed region.
+template <int T>
+int set_sha_attrs(zke_engine* e) {
+  HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&sha256_batch_kernel<T>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sha256_lds_bytes<T>()));
+  HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&sha256_pair_kernel<T>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sha256_pair_lds_bytes<T>()));
+  return 0;
+}
+
 template <int T>
 int launch_sha(zke_engine* e, const ShaJob* jobs, uint32_t n, hipStream_t s) {
   if (n == 0) return 0;
-  static bool attr_set = false;
   const size_t lds = sha256_lds_bytes<T>();
-  if (!attr_set) {
-    HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&sha256_batch_kernel<T>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
   // Few messages: the launch is as long as one wave's chain of compressions, so split the chain over two waves
   // (sha256_pair_kernel).  Many messages: the chip is full and the one-wave kernel does less LDS work per byte.
   const uint32_t groups = (n + 63) / 64;
   if (e->sha_pair == 1 || (e->sha_pair < 0 && groups <= SHA_PAIR_MAX_GROUPS)) {
-    static bool pair_attr_set = false;
     const size_t plds = sha256_pair_lds_bytes<T>();
-    if (!pair_attr_set) {
-      HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&sha256_pair_kernel<T>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
-      pair_attr_set = true;
-    }
     hipLaunchKernelGGL(sha256_pair_kernel<T>, dim3(groups), dim3(128), plds, s, jobs, n);
     HIPCHK(e, hipGetLastError());
     return 0;
@@ -142,6 +155,8 @@ int launch_sha(zke_engine* e, const ShaJob* jobs, uint32_t n, hipStream_t s) {
   return 0;
 }
 
+int set_kernel_attrs(zke_engine* e);      // pipeline.hip.h
+
 // tile size is a tuning knob (LDS per wave = 64 * (T + 16) bytes sets the occupancy); ZKE_SHA_TILE overrides for experiments
 int launch_sha_any(zke_engine* e, const ShaJob* jobs, uint32_t n, hipStream_t s) {
   switch (e->sha_tile) {
@@ -150,6 +165,32 @@ int launch_sha_any(zke_engine* e, const ShaJob* jobs, uint32_t n, hipStream_t s)
     case 512: return launch_sha<512>(e, jobs, n, s);
     default: return launch_sha<SHA_TILE>(e, jobs, n, s);
   }
+}
+int set_sha_attrs_any(zke_engine* e) {
+  switch (e->sha_tile) {
+    case 64: return set_sha_attrs<64>(e);
+    case 256: return set_sha_attrs<256>(e);
+    case 512: return set_sha_attrs<512>(e);
+    default: e->sha_tile = SHA_TILE; return set_sha_attrs<SHA_TILE>(e);
+  }
+}
+
+Slot* new_slot(zke_engine* e) {
+  Slot* w = new Slot();
+  bool ok = hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&w->done, hipEventDisableTiming) == hipSuccess;
+  for (auto& ev : w->ev) ok = ok && hipEventCreate(&ev) == hipSuccess;
+  if (!ok) { e->err = "slot stream / event creation"; delete w; return nullptr; }
+  return w;
+}
+void free_slot(Slot* w) {
+  if (!w) return;
+  if (w->stream) (void)hipStreamSynchronize(w->stream);
+  for (auto* b : w->all) b->release();
+  for (auto& ev : w->ev) if (ev) (void)hipEventDestroy(ev);
+  if (w->done) (void)hipEventDestroy(w->done);
+  if (w->stream) (void)hipStreamDestroy(w->stream);
+  delete w;
 }
 
 // key_hash_base: &results[0].public_key_hash (same stride as hash_base) or nullptr = no key cache;
@@ -204,9 +245,11 @@ int zke_engine_create(const zke_options* opt, zke_engine** out) {
   if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
   e->device = dev;
   if (hipSetDevice(dev) != hipSuccess) { delete e; return ZKE_E_DEVICE; }
-  if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return ZKE_E_DEVICE; }
-  for (auto& ev : e->ev) if (hipEventCreate(&ev) != hipSuccess) { delete e; return ZKE_E_DEVICE; }
-  for (auto& ev : e->ev_h2d) if (hipEventCreate(&ev) != hipSuccess) { delete e; return ZKE_E_DEVICE; }
+  Slot* w0 = new_slot(e);
+  if (!w0) { delete e; return ZKE_E_DEVICE; }
+  e->slots.push_back(w0);
+  e->stream = w0->stream;
+  for (auto& ev : e->ev_h2d) if (hipEventCreate(&ev) != hipSuccess) { zke_engine_destroy(e); return ZKE_E_DEVICE; }
   if (!(opt && opt->reserved[3])) {      // reserved[3] != 0: no per-key cache (R^2 mod n recomputed per signature)
     if (e->key_cache.ensure((size_t)KEY_CACHE_SLOTS * sizeof(KeyCacheEntry)) ||
         hipMemset(e->key_cache.p, 0, (size_t)KEY_CACHE_SLOTS * sizeof(KeyCacheEntry)) != hipSuccess) {
@@ -227,6 +270,7 @@ int zke_engine_create(const zke_options* opt, zke_engine** out) {
   if (getenv("ZKE_DEBUG_SKIP_ED")) e->debug_skip_ed = 1;
   if (getenv("ZKE_NO_FUSE_CANON")) e->fuse_canon = 0;
   if (const char* ds = getenv("ZKE_DEBUG_PARSE_STOP")) e->debug_parse_stop = (uint32_t)atoi(ds);
+  if (set_kernel_attrs(e)) { zke_engine_destroy(e); return ZKE_E_DEVICE; }
   *out = e;
   return 0;
 }
@@ -234,16 +278,12 @@ int zke_engine_create(const zke_options* opt, zke_engine** out) {
 void zke_engine_destroy(zke_engine* e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
-  (void)hipStreamSynchronize(e->stream);
+  for (Slot* w : e->slots) free_slot(w);
   DevBuf* bufs[] = {&e->in_raw, &e->in_raw_off, &e->in_dom, &e->in_dom_off, &e->in_key, &e->in_key_off, &e->in_ktype,
-                    &e->in_extnull, &e->in_cap_off, &e->in_cap_str_off, &e->in_cap_blob, &e->results, &e->meta,
-                    &e->rsa_jobs, &e->sha_jobs, &e->rsa_ok, &e->em_dbg, &e->scratch_off, &e->scratch, &e->clean,
-                    &e->meta2, &e->misc, &e->scratch2, &e->parts, &e->pending, &e->key_cache, &e->lanews};
+                    &e->in_extnull, &e->in_cap_off, &e->in_cap_str_off, &e->in_cap_blob, &e->results, &e->misc, &e->key_cache};
   for (auto* b : bufs) b->release();
   for (auto* d : e->dfas) { d->blob.release(); d->dev.release(); delete d; }
-  for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : e->ev_h2d) if (ev) (void)hipEventDestroy(ev);
-  if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
 
@@ -251,7 +291,12 @@ const char* zke_last_error(const zke_engine* e) { return e ? e->err.c_str() : "n
 
 int zke_engine_sync(zke_engine* e) {
   if (!e) return ZKE_E_ARG;
-  HIPCHK(e, hipStreamSynchronize(e->stream));
+  HIPCHK(e, hipSetDevice(e->device));
+  for (Slot* w : e->slots) {
+    // a slot's last batch ran on the slot's own stream, or on a caller's stream with `done` recorded behind it
+    if (w->last_stream && w->last_stream != w->stream) HIPCHK(e, hipEventSynchronize(w->done));
+    HIPCHK(e, hipStreamSynchronize(w->stream));
+  }
   return 0;
 }
 
@@ -261,14 +306,20 @@ int zke_set_timing(zke_engine* e, int enabled) {
   return 0;
 }
 
-int zke_get_timings(zke_engine* e, zke_timings* t) {
-  if (!e || !t) return ZKE_E_ARG;
-  if (e->timing && e->timed_marks > 0) {     // device-mode batches: the events are read once their stream has drained
-    HIPCHK(e, hipEventSynchronize(e->ev[e->timed_marks - 1]));
-    collect_timings(e);
+int zke_get_slot_timings(zke_engine* e, uint32_t slot, zke_timings* t) {
+  if (!e || !t || slot >= e->slots.size()) return ZKE_E_ARG;
+  Slot& w = *e->slots[slot];
+  if (e->timing && w.timed_marks > 0) {     // device-mode batches: the events are read once their stream has drained
+    HIPCHK(e, hipEventSynchronize(w.ev[w.timed_marks - 1]));
+    collect_timings(e, w);
   }
   *t = e->last;
   return 0;
+}
+
+int zke_get_timings(zke_engine* e, zke_timings* t) {
+  if (!e) return ZKE_E_ARG;
+  return zke_get_slot_timings(e, e->last_slot, t);
 }
 
 // ---------------------------------------------------------------- building blocks

@@ -10,42 +10,66 @@ constexpr size_t FRONT_LDS_BYTES = (size_t)64 * FRONT_ROW;
 inline uint64_t host_scratch_off(const uint64_t* raw_off, uint32_t i) { return scratch_offset(raw_off[i] - raw_off[0], i); }
 
 struct StageTimer {
-  zke_engine* e; hipStream_t s; int k = 0; bool on;
-  StageTimer(zke_engine* e_, hipStream_t s_) : e(e_), s(s_), on(e_->timing) {}
-  void mark() { if (on && k < 16) (void)hipEventRecord(e->ev[k++], s); }
+  Slot* w; hipStream_t s; int k = 0; bool on;
+  StageTimer(zke_engine* e_, Slot* w_, hipStream_t s_) : w(w_), s(s_), on(e_->timing) {}
+  void mark() { if (on && k < 16) (void)hipEventRecord(w->ev[k++], s); }
 };
+
+// Workspace of one slot for batches of up to n e-mails / raw_total raw bytes (P regex parts; with_regex: the buffers of
+// the canonicalize_signed_email pass too).  Grows only: in steady state — or after zke_engine_reserve — this allocates nothing.
+int ensure_workspace(zke_engine* e, Slot& w, uint32_t n, uint64_t raw_total, bool with_regex, uint32_t P, bool want_em) {
+  const uint32_t n_pad = (n + 63) & ~63u;
+  int r = 0;
+  const size_t scratch_bytes = 2 * (size_t)raw_total + (size_t)(n + 1) * SCR_PER_EMAIL + 256;
+  if ((r = w.meta.ensure((size_t)n * sizeof(EmailMeta))) || (r = w.rsa_jobs.ensure((size_t)n * sizeof(RsaJob))) ||
+      (r = w.sha_jobs.ensure((size_t)4 * n_pad * sizeof(ShaJob))) || (r = w.rsa_ok.ensure((size_t)n * 4)) ||
+      (r = w.scratch_off.ensure((size_t)(n + 1) * 16)) || (r = w.scratch.ensure(scratch_bytes)) || (r = w.pending.ensure(64)))
+    return fail(e, r, "workspace allocation");
+  if (!e->wave_parse && (r = w.lanews.ensure((size_t)n * sizeof(LaneWs)))) return fail(e, r, "workspace allocation");
+  if (want_em && (r = w.em_dbg.ensure((size_t)n * 512))) return fail(e, r, "workspace allocation");
+  if (with_regex) {
+    if ((r = w.meta2.ensure((size_t)n * sizeof(EmailMeta))) || (r = w.scratch2.ensure(scratch_bytes)) ||
+        (r = w.clean.ensure((size_t)raw_total + (size_t)(n + 1) * CLEAN_PER_EMAIL + 256)) ||
+        (r = w.parts.ensure((size_t)n * std::max<uint32_t>(P, 1) * sizeof(PartRes))))
+      return fail(e, r, "workspace allocation");
+  }
+  return 0;
+}
+
+// Every hipFuncSetAttribute the pipeline needs, once per engine (= per device).  The DFA kernels' LDS sizes depend on
+// the registered tables: zke_dfa_register raises them.
+int set_kernel_attrs(zke_engine* e) {
+  if (int r = set_sha_attrs_any(e)) return r;
+  HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&front_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FRONT_LDS_BYTES));
+  return 0;
+}
+int raise_dfa_lds_attrs(zke_engine* e, size_t lds) {
+  if (lds > e->dfa_wave_lds_attr) {
+    HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&dfa_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    e->dfa_wave_lds_attr = lds;
+  }
+  if (lds > e->dfa_lds_attr) {
+    HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&dfa_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    e->dfa_lds_attr = lds;
+  }
+  return 0;
+}
 
 // The device pipeline.  Every pointer in `in` / out_dev is device memory.
 // Signature rounds [round_begin, round_end) of verify_email_with_key run here; the regex stage runs when
 // `with_regex_stage` is set (after the last round the caller intends to run).
-int run_device_pipeline(zke_engine* e, const zke_batch* in, uint64_t raw_total, zke_result* out_dev, hipStream_t s,
+int run_device_pipeline(zke_engine* e, Slot& w, const zke_batch* in, uint64_t raw_total, zke_result* out_dev, hipStream_t s,
                         bool want_em, uint32_t round_begin, uint32_t round_end, uint32_t max_rounds, bool with_regex_stage) {
   const uint32_t n = in->n;
   if (n == 0) return 0;
   const uint32_t n_pad = (n + 63) & ~63u;
   const uint32_t P = in->with_regex ? in->n_header_parts + in->n_body_parts : 0;
   int r = 0;
-  const size_t scratch_bytes = 2 * (size_t)raw_total + (size_t)(n + 1) * SCR_PER_EMAIL + 256;
-  if ((r = e->meta.ensure((size_t)n * sizeof(EmailMeta))) || (r = e->rsa_jobs.ensure((size_t)n * sizeof(RsaJob))) ||
-      (r = e->sha_jobs.ensure((size_t)4 * n_pad * sizeof(ShaJob))) || (r = e->rsa_ok.ensure((size_t)n * 4)) ||
-      (r = e->scratch_off.ensure((size_t)(n + 1) * 16)) || (r = e->scratch.ensure(scratch_bytes)) || (r = e->pending.ensure(64)) ||
-      (r = e->lanews.ensure((size_t)n * sizeof(LaneWs))))
-    return fail(e, r, "workspace allocation");
-  if (want_em && (r = e->em_dbg.ensure((size_t)n * 512))) return fail(e, r, "workspace allocation");
-  if (in->with_regex) {
-    if ((r = e->meta2.ensure((size_t)n * sizeof(EmailMeta))) || (r = e->scratch2.ensure(scratch_bytes)) ||
-        (r = e->clean.ensure((size_t)raw_total + (size_t)(n + 1) * CLEAN_PER_EMAIL + 256)) ||
-        (r = e->parts.ensure((size_t)n * std::max<uint32_t>(P, 1) * sizeof(PartRes))))
-      return fail(e, r, "workspace allocation");
-  }
-  uint64_t* scratch_off = e->scratch_off.as<uint64_t>();
+  if ((r = ensure_workspace(e, w, n, raw_total, in->with_regex != 0, P, want_em))) return r;
+  uint64_t* scratch_off = w.scratch_off.as<uint64_t>();
   uint64_t* clean_off = scratch_off + (n + 1);
 
-  if (!e->front_attr_set) {
-    HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&front_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FRONT_LDS_BYTES));
-    e->front_attr_set = true;
-  }
-  StageTimer tm(e, s);
+  StageTimer tm(e, &w, s);
   tm.mark();
   // (offsets, padding SHA jobs and the pending counter are initialised by the round-0 front-end kernel: batch_prologue)
 
@@ -56,14 +80,14 @@ int run_device_pipeline(zke_engine* e, const zke_batch* in, uint64_t raw_total, 
   B.key = in->key_blob; B.key_off = in->key_off;
   B.key_type = in->key_type; B.ext_null = in->ext_null;
   B.results = out_dev;
-  B.meta = e->meta.as<EmailMeta>();
-  B.rsa = e->rsa_jobs.as<RsaJob>();
-  B.sha = e->sha_jobs.as<ShaJob>();
+  B.meta = w.meta.as<EmailMeta>();
+  B.rsa = w.rsa_jobs.as<RsaJob>();
+  B.sha = w.sha_jobs.as<ShaJob>();
   B.n_pad = n_pad;
-  B.scratch = e->scratch.as<uint8_t>();
+  B.scratch = w.scratch.as<uint8_t>();
   B.scratch_off = scratch_off;
   B.clean_off = clean_off;
-  B.pending = e->pending.as<uint32_t>();
+  B.pending = w.pending.as<uint32_t>();
   B.meta_verify = nullptr;
 
   const uint32_t rounds = max_rounds;
@@ -72,7 +96,7 @@ int run_device_pipeline(zke_engine* e, const zke_batch* in, uint64_t raw_total, 
       ParseArgs pa{B, round, 0, e->debug_parse_stop, e->fuse_canon};
       hipLaunchKernelGGL(parse_kernel, dim3(n), dim3(64), 0, s, pa);
     } else {
-      FrontArgs fa{B, e->lanews.as<LaneWs>(), round, 0, e->debug_parse_stop};
+      FrontArgs fa{B, w.lanews.as<LaneWs>(), round, 0, e->debug_parse_stop};
       hipLaunchKernelGGL(front_kernel, dim3((n + 63) / 64), dim3(64), FRONT_LDS_BYTES, s, fa);
     }
     if (round == 0) tm.mark();
@@ -87,9 +111,9 @@ int run_device_pipeline(zke_engine* e, const zke_batch* in, uint64_t raw_total, 
       EdArgs ea{B, round};        // Ed25519 keys / signatures (lane per e-mail); all-RSA waves exit after one load
       hipLaunchKernelGGL(ed25519_email_kernel, dim3((n + 63) / 64), dim3(64), 0, s, ea);
     }
-    FinArgs fa{B, round, rounds, e->pending.as<uint32_t>(), e->debug_skip_rsa};
+    FinArgs fa{B, round, rounds, w.pending.as<uint32_t>(), e->debug_skip_rsa};
     if ((r = launch_rsa(e, B.rsa, n, reinterpret_cast<const uint8_t*>(out_dev) + offsetof(zke_result, header_hash),
-                        sizeof(zke_result), nullptr, want_em ? e->em_dbg.as<uint8_t>() : nullptr, s,
+                        sizeof(zke_result), nullptr, want_em ? w.em_dbg.as<uint8_t>() : nullptr, s,
                         e->batch_key_total > (uint64_t)n * 272 /* an RSA-2048 key is 270 bytes of DER: some key is larger */,
                         e->key_cache.p ? reinterpret_cast<const uint8_t*>(out_dev) + offsetof(zke_result, public_key_hash) : nullptr, fa)))
       return r;
@@ -100,19 +124,19 @@ int run_device_pipeline(zke_engine* e, const zke_batch* in, uint64_t raw_total, 
   if (in->with_regex && with_regex_stage) {
     // canonicalize_signed_email (circuits.rs:34-35): first DKIM-Signature header, own scratch unless it is the verified one
     BatchDev B2 = B;
-    B2.meta = e->meta2.as<EmailMeta>();
-    B2.scratch = e->scratch2.as<uint8_t>();
+    B2.meta = w.meta2.as<EmailMeta>();
+    B2.scratch = w.scratch2.as<uint8_t>();
     B2.meta_verify = B.meta;
     if (e->wave_parse) {
       ParseArgs pa{B2, 0, 1, 0, 0};
       hipLaunchKernelGGL(parse_kernel, dim3(n), dim3(64), 0, s, pa);
     } else {
-      FrontArgs fa{B2, e->lanews.as<LaneWs>(), 0, 1, 0};
+      FrontArgs fa{B2, w.lanews.as<LaneWs>(), 0, 1, 0};
       hipLaunchKernelGGL(front_kernel, dim3((n + 63) / 64), dim3(64), FRONT_LDS_BYTES, s, fa);
     }
     CanonArgs ca{B2, 1};
     hipLaunchKernelGGL(canon_body_kernel, dim3(n), dim3(64), 0, s, ca);
-    QpArgs qa{B2, B.meta, e->clean.as<uint8_t>(), clean_off, B.scratch, B.scratch_off};
+    QpArgs qa{B2, B.meta, w.clean.as<uint8_t>(), clean_off, B.scratch, B.scratch_off};
     hipLaunchKernelGGL(qp_kernel, dim3(n), dim3(64), 0, s, qa);    // circuits.rs:37 runs whether or not body parts exist
     tm.mark();
     auto part_dfa = [&](uint32_t p) -> const RegisteredDfa* {
@@ -123,9 +147,9 @@ int run_device_pipeline(zke_engine* e, const zke_batch* in, uint64_t raw_total, 
     DfaArgs base{};
     base.b = B2; base.P = P;
     base.scratch_v = B.scratch; base.scratch_v_off = B.scratch_off;
-    base.clean = e->clean.as<uint8_t>(); base.clean_off = clean_off;
+    base.clean = w.clean.as<uint8_t>(); base.clean_off = clean_off;
     base.cap_off = in->cap_off; base.cap_str_off = in->cap_str_off; base.cap_blob = in->cap_blob;
-    base.out = e->parts.as<PartRes>();
+    base.out = w.parts.as<PartRes>();
     auto part_lds = [&](const RegisteredDfa* rd, uint32_t& in_lds) -> size_t {
       in_lds = 0;
       if (rd && rd->valid && rd->lds_bytes + 1024 <= 150 * 1024) { in_lds = 1; return rd->lds_bytes + 1024; }
@@ -150,10 +174,6 @@ int run_device_pipeline(zke_engine* e, const zke_batch* in, uint64_t raw_total, 
           lds = std::max(lds, part_lds(rd, ma.lds_tables[k]));
           ma.idle[k] = (rd && rd->valid) ? rd->idle : 0xFFFFFFFFu;
         }
-        if (lds > e->dfa_wave_lds_attr) {
-          HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&dfa_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          e->dfa_wave_lds_attr = lds;
-        }
         hipLaunchKernelGGL(dfa_wave_kernel, dim3((n + 3) / 4, np), dim3(256), lds, s, ma);
       }
     }
@@ -164,33 +184,42 @@ int run_device_pipeline(zke_engine* e, const zke_batch* in, uint64_t raw_total, 
         da.re = (rd && rd->valid) ? rd->dev.as<RegexDev>() : nullptr;
         da.part = p; da.is_body = p >= in->n_header_parts ? 1 : 0;
         const size_t lds = part_lds(rd, da.lds_tables);
-        if (lds > e->dfa_lds_attr) {
-          HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&dfa_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          e->dfa_lds_attr = lds;
-        }
         da.idle = 0xFFFFFFFFu;
         hipLaunchKernelGGL(dfa_kernel, dim3((n + 255) / 256), dim3(256), lds, s, da);
       }
     }
-    RegexFinArgs rf{B2, e->parts.as<PartRes>(), in->n_header_parts, in->n_body_parts};
+    RegexFinArgs rf{B2, w.parts.as<PartRes>(), in->n_header_parts, in->n_body_parts};
     hipLaunchKernelGGL(regex_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, s, rf);
     tm.mark();
     HIPCHK(e, hipGetLastError());
   }
   tm.mark();
-  e->timed_marks = tm.k;
-  e->timed_regex = in->with_regex != 0;
+  w.timed_marks = tm.k;
+  w.timed_regex = in->with_regex != 0;
   return 0;
 }
 
-void collect_timings(zke_engine* e) {
-  if (!e->timing || e->timed_marks < 7) return;
-  auto dt = [&](int a, int b) { float ms = 0; (void)hipEventElapsedTime(&ms, e->ev[a], e->ev[b]); return ms * 1000.f; };
+void collect_timings(zke_engine* e, Slot& w) {
+  if (!e->timing || w.timed_marks < 7) return;
+  auto dt = [&](int a, int b) { float ms = 0; (void)hipEventElapsedTime(&ms, w.ev[a], w.ev[b]); return ms * 1000.f; };
   zke_timings& t = e->last;
   t.parse_us = dt(0, 1); t.canon_body_us = dt(1, 2); t.sha_us = dt(2, 3); t.rsa_us = dt(3, 4); t.finalize_us = dt(4, 5);
-  if (e->timed_regex && e->timed_marks >= 9) { t.qp_us = dt(5, 6); t.dfa_us = dt(6, 7); }
+  if (w.timed_regex && w.timed_marks >= 9) { t.qp_us = dt(5, 6); t.dfa_us = dt(6, 7); }
   else { t.qp_us = 0; t.dfa_us = 0; }
-  t.total_us = dt(0, e->timed_marks - 1);
+  t.total_us = dt(0, w.timed_marks - 1);
+}
+
+// The slot's workspace is about to be overwritten by a batch on stream s: whatever ran in it before must be over.
+// Same stream: stream order is enough.  Another stream: wait for the event recorded behind the previous batch.
+int acquire_slot(zke_engine* e, Slot& w, hipStream_t s) {
+  if (w.last_stream && w.last_stream != s) HIPCHK(e, hipStreamWaitEvent(s, w.done, 0));
+  return 0;
+}
+int release_slot(zke_engine* e, Slot& w, hipStream_t s) {
+  // the event is needed only where the next user of the slot may sit on another stream: a caller-provided stream
+  if (s != w.stream) HIPCHK(e, hipEventRecord(w.done, s));
+  w.last_stream = s;
+  return 0;
 }
 
 // ---- regex-automata 0.4.9 dense DFA, little-endian wire format ----
@@ -325,7 +354,18 @@ extern "C" {
 int zke_dfa_register(zke_engine* e, const uint8_t* fwd, size_t fwd_len, const uint8_t* bwd, size_t bwd_len, uint32_t* out_id) {
   if (!e || !out_id || (fwd_len && !fwd) || (bwd_len && !bwd)) return ZKE_E_ARG;
   HIPCHK(e, hipSetDevice(e->device));
+  // registering the same pair again returns the id it already has (per-e-mail callers re-submit their part list)
+  for (size_t k = 0; k < e->dfas.size(); k++) {
+    const RegisteredDfa* d = e->dfas[k];
+    if (d->fwd_copy.size() == fwd_len && d->bwd_copy.size() == bwd_len && (!fwd_len || !memcmp(d->fwd_copy.data(), fwd, fwd_len)) &&
+        (!bwd_len || !memcmp(d->bwd_copy.data(), bwd, bwd_len))) {
+      *out_id = (uint32_t)k;
+      return 0;
+    }
+  }
   RegisteredDfa* rd = new RegisteredDfa();
+  rd->fwd_copy.assign(fwd, fwd + fwd_len);
+  rd->bwd_copy.assign(bwd, bwd + bwd_len);
   HostDfa hf, hr;
   const bool ok = parse_dfa_blob(fwd, fwd_len, hf) && parse_dfa_blob(bwd, bwd_len, hr);
   rd->valid = ok;
@@ -350,27 +390,53 @@ int zke_dfa_register(zke_engine* e, const uint8_t* fwd, size_t fwd_len, const ui
     if (he == hipSuccess) he = hipMemcpy(rd->dev.p, &rdv, sizeof rdv, hipMemcpyHostToDevice);
     if (he != hipSuccess) { rd->blob.release(); rd->dev.release(); delete rd; return fail(e, ZKE_E_DEVICE, "dfa upload", he); }
   }
+  if (ok && rd->lds_bytes + 1024 <= 150 * 1024) {      // the tables fit in LDS: the DFA kernels are launched with that much
+    if (int r = raise_dfa_lds_attrs(e, rd->lds_bytes + 1024)) { rd->blob.release(); rd->dev.release(); delete rd; return r; }
+  }
   e->dfas.push_back(rd);
   *out_id = (uint32_t)(e->dfas.size() - 1);
+  return 0;
+}
+
+int zke_engine_reserve(zke_engine* e, uint32_t max_n, uint64_t max_raw_total, uint32_t slots, uint32_t max_regex_parts) {
+  if (!e || slots == 0 || slots > 64) return ZKE_E_ARG;
+  HIPCHK(e, hipSetDevice(e->device));
+  while (e->slots.size() < slots) {
+    Slot* w = new_slot(e);
+    if (!w) return ZKE_E_DEVICE;
+    e->slots.push_back(w);
+  }
+  if (max_n)
+    for (Slot* w : e->slots)
+      if (int r = ensure_workspace(e, *w, max_n, max_raw_total, max_regex_parts != 0, max_regex_parts, false)) return r;
   return 0;
 }
 
 int zke_verify_batch_device(zke_engine* e, const zke_batch* in, uint64_t raw_total, uint64_t domain_total, uint64_t key_total,
                             zke_result* out_dev, void* stream) {
   (void)domain_total;
-  e->batch_key_total = key_total;
-  if (!e || !in || (in->n && (!out_dev || !in->raw_blob || !in->raw_off || !in->domain_off || !in->key_off || !in->key_type)))
-    return ZKE_E_ARG;
+  if (!e) return ZKE_E_ARG;
+  if (!in || (in->n && (!out_dev || !in->raw_blob || !in->raw_off || !in->domain_off || !in->key_off || !in->key_type)))
+    return fail(e, ZKE_E_ARG, "zke_verify_batch_device: null pointer");
+  if (in->with_regex && ((in->n_header_parts && !in->header_part_ids) || (in->n_body_parts && !in->body_part_ids)))
+    return fail(e, ZKE_E_ARG, "zke_verify_batch_device: part-id list is null");
   HIPCHK(e, hipSetDevice(e->device));
+  e->batch_key_total = key_total;
   // the part-id lists are small host arrays even in device mode
   e->host_hdr_ids.assign(in->header_part_ids, in->header_part_ids + (in->with_regex ? in->n_header_parts : 0));
   e->host_body_ids.assign(in->body_part_ids, in->body_part_ids + (in->with_regex ? in->n_body_parts : 0));
   // device mode runs a fixed number of signature rounds (options.reserved[1], default 1) without reading anything back
   const uint32_t rounds = e->device_mode_rounds;
-  hipStream_t s = stream ? (hipStream_t)stream : e->stream;
-  // Launched eagerly: four kernels per batch (five or six when the lane-group RSA kernels take part: batches >= 2 048).  (A hipGraph capture / replay of this sequence was tried in round 1:
-  // the eager path is not host-bound, and the replay faulted — it was removed rather than kept as a switch.)
-  return run_device_pipeline(e, in, raw_total, out_dev, s, false, 0, rounds, rounds, true);
+  // Submission slots are taken round-robin: with S slots, S batches are in flight before a workspace is reused.
+  const uint32_t slot = e->next_slot;
+  e->next_slot = (slot + 1) % (uint32_t)e->slots.size();
+  e->last_slot = slot;
+  Slot& w = *e->slots[slot];
+  hipStream_t s = stream ? (hipStream_t)stream : w.stream;
+  if (int r = acquire_slot(e, w, s)) return r;
+  // Launched eagerly: four kernels per batch (five or six when the lane-group RSA kernels take part: batches >= 2 048).
+  if (int r = run_device_pipeline(e, w, in, raw_total, out_dev, s, false, 0, rounds, rounds, true)) return r;
+  return release_slot(e, w, s);
 }
 
 int zke_verify_batch(zke_engine* e, const zke_batch* in, zke_result* out, zke_debug_out* dbg) {
@@ -379,8 +445,14 @@ int zke_verify_batch(zke_engine* e, const zke_batch* in, zke_result* out, zke_de
     return ZKE_E_ARG;
   const uint32_t n = in->n;
   if (n == 0) return 0;
+  if (in->with_regex && ((in->n_header_parts && !in->header_part_ids) || (in->n_body_parts && !in->body_part_ids)))
+    return fail(e, ZKE_E_ARG, "zke_verify_batch: part-id list is null");
   HIPCHK(e, hipSetDevice(e->device));
-  hipStream_t s = e->stream;
+  Slot& w = *e->slots[0];            // host-mode batches are synchronous: always slot 0, on its own stream
+  hipStream_t s = w.stream;
+  e->last_slot = 0;
+  if (int ar = acquire_slot(e, w, s)) return ar;
+  w.last_stream = s;
   const uint64_t raw_total = in->raw_off[n] - in->raw_off[0], dom_total = in->domain_off[n] - in->domain_off[0],
                  key_total = in->key_off[n] - in->key_off[0];
   e->batch_key_total = key_total;
@@ -439,20 +511,20 @@ int zke_verify_batch(zke_engine* e, const zke_batch* in, zke_result* out, zke_de
   for (;;) {
     const bool last_possible = round + 1 >= max_rounds;
     // the regex stage must follow the final verdicts: run it with this round only if no further round can follow
-    if ((r = run_device_pipeline(e, &dv, raw_total, e->results.as<zke_result>(), s, want_em, round, round + 1, max_rounds,
+    if ((r = run_device_pipeline(e, w, &dv, raw_total, e->results.as<zke_result>(), s, want_em, round, round + 1, max_rounds,
                                  last_possible)))
       return r;
     if (last_possible) break;
     uint32_t pending = 0;
-    HIPCHK(e, hipMemcpyAsync(&pending, e->pending.p, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(e, hipMemcpyAsync(&pending, w.pending.p, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(e, hipStreamSynchronize(s));
     if (pending == 0) {
-      if (in->with_regex && (r = run_device_pipeline(e, &dv, raw_total, e->results.as<zke_result>(), s, want_em, round + 1,
+      if (in->with_regex && (r = run_device_pipeline(e, w, &dv, raw_total, e->results.as<zke_result>(), s, want_em, round + 1,
                                                      round + 1, max_rounds, true)))
         return r;
       break;
     }
-    HIPCHK(e, hipMemsetAsync(e->pending.p, 0, 8, s));
+    HIPCHK(e, hipMemsetAsync(w.pending.p, 0, 8, s));
     round++;
   }
   if (e->timing) (void)hipEventRecord(d0, s);
@@ -461,7 +533,7 @@ int zke_verify_batch(zke_engine* e, const zke_batch* in, zke_result* out, zke_de
   if (e->timing) {
     (void)hipEventRecord(d1, s);
     (void)hipEventSynchronize(d1);
-    collect_timings(e);
+    collect_timings(e, w);
     float ms = 0;
     (void)hipEventElapsedTime(&ms, h0, h1); e->last.h2d_us = ms * 1000.f;
     (void)hipEventElapsedTime(&ms, d0, d1); e->last.d2h_us = ms * 1000.f;
@@ -469,17 +541,17 @@ int zke_verify_batch(zke_engine* e, const zke_batch* in, zke_result* out, zke_de
 
   if (dbg) {   // parity intermediates: copy the scratch back and slice it on the host
     std::vector<EmailMeta> meta(n), meta2;
-    HIPCHK(e, hipMemcpy(meta.data(), e->meta.p, (size_t)n * sizeof(EmailMeta), hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(meta.data(), w.meta.p, (size_t)n * sizeof(EmailMeta), hipMemcpyDeviceToHost));
     const size_t scratch_bytes = 2 * (size_t)raw_total + (size_t)(n + 1) * SCR_PER_EMAIL + 256;
     std::vector<uint8_t> scr(scratch_bytes);
-    HIPCHK(e, hipMemcpy(scr.data(), e->scratch.p, scratch_bytes, hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(scr.data(), w.scratch.p, scratch_bytes, hipMemcpyDeviceToHost));
     std::vector<uint8_t> em, clean;
-    if (dbg->em) { em.resize((size_t)n * 512); HIPCHK(e, hipMemcpy(em.data(), e->em_dbg.p, em.size(), hipMemcpyDeviceToHost)); }
+    if (dbg->em) { em.resize((size_t)n * 512); HIPCHK(e, hipMemcpy(em.data(), w.em_dbg.p, em.size(), hipMemcpyDeviceToHost)); }
     if (dbg->clean_body && in->with_regex) {
       meta2.resize(n);
-      HIPCHK(e, hipMemcpy(meta2.data(), e->meta2.p, (size_t)n * sizeof(EmailMeta), hipMemcpyDeviceToHost));
+      HIPCHK(e, hipMemcpy(meta2.data(), w.meta2.p, (size_t)n * sizeof(EmailMeta), hipMemcpyDeviceToHost));
       clean.resize((size_t)raw_total + (size_t)(n + 1) * CLEAN_PER_EMAIL + 256);
-      HIPCHK(e, hipMemcpy(clean.data(), e->clean.p, clean.size(), hipMemcpyDeviceToHost));
+      HIPCHK(e, hipMemcpy(clean.data(), w.clean.p, clean.size(), hipMemcpyDeviceToHost));
     }
     auto put = [](uint8_t* base, size_t stride, uint32_t i, const uint8_t* src, size_t len) {
       if (!base) return;
@@ -507,18 +579,69 @@ int zke_verify_batch(zke_engine* e, const zke_batch* in, zke_result* out, zke_de
   return 0;
 }
 
-int zke_verify_email(zke_engine* e, const uint8_t* raw, size_t raw_len, const char* from_domain, size_t domain_len,
-                     const uint8_t* key, size_t key_len, uint32_t key_type, zke_result* out) {
-  if (!e || !out) return ZKE_E_ARG;
-  const uint64_t ro[2] = {0, raw_len}, dofs[2] = {0, domain_len}, ko[2] = {0, key_len};
-  const uint8_t kt = (uint8_t)key_type;
-  static const uint8_t dummy = 0;
+// ---- single-e-mail wrappers: a batch of one (config 1 and API-shape parity)
+namespace {
+struct OneEmail {
+  uint64_t ro[2], dofs[2], ko[2];
+  uint8_t kt, ext;
   zke_batch b{};
-  b.n = 1;
-  b.raw_blob = raw ? raw : &dummy; b.raw_off = ro;
-  b.domain_blob = from_domain ? reinterpret_cast<const uint8_t*>(from_domain) : &dummy; b.domain_off = dofs;
-  b.key_blob = key ? key : &dummy; b.key_off = ko;
-  b.key_type = &kt;
+  OneEmail(const uint8_t* raw, size_t raw_len, const char* from_domain, size_t domain_len, const uint8_t* key, size_t key_len,
+           uint32_t key_type, uint32_t external_input_null)
+      : ro{0, raw_len}, dofs{0, domain_len}, ko{0, key_len}, kt((uint8_t)(key_type > ZKE_KEY_OTHER ? ZKE_KEY_OTHER : key_type)),
+        ext(external_input_null ? 1 : 0) {
+    static const uint8_t dummy = 0;
+    b.n = 1;
+    b.raw_blob = raw ? raw : &dummy; b.raw_off = ro;
+    b.domain_blob = from_domain ? reinterpret_cast<const uint8_t*>(from_domain) : &dummy; b.domain_off = dofs;
+    b.key_blob = key ? key : &dummy; b.key_off = ko;
+    b.key_type = &kt; b.ext_null = &ext;
+  }
+};
+}  // namespace
+
+int zke_verify_email(zke_engine* e, const uint8_t* raw, size_t raw_len, const char* from_domain, size_t domain_len,
+                     const uint8_t* key, size_t key_len, uint32_t key_type, uint32_t external_input_null, zke_result* out) {
+  if (!e) return ZKE_E_ARG;
+  if (!out || (raw_len && !raw) || (domain_len && !from_domain) || (key_len && !key)) return fail(e, ZKE_E_ARG, "zke_verify_email: null pointer");
+  OneEmail one(raw, raw_len, from_domain, domain_len, key, key_len, key_type, external_input_null);
+  return zke_verify_batch(e, &one.b, out, nullptr);
+}
+
+int zke_verify_email_with_regex(zke_engine* e, const uint8_t* raw, size_t raw_len, const char* from_domain, size_t domain_len,
+                                const uint8_t* key, size_t key_len, uint32_t key_type, uint32_t external_input_null,
+                                const zke_regex_part* header_parts, uint32_t n_header_parts,
+                                const zke_regex_part* body_parts, uint32_t n_body_parts, zke_result* out) {
+  if (!e) return ZKE_E_ARG;
+  if (!out || (raw_len && !raw) || (domain_len && !from_domain) || (key_len && !key) || (n_header_parts && !header_parts) ||
+      (n_body_parts && !body_parts))
+    return fail(e, ZKE_E_ARG, "zke_verify_email_with_regex: null pointer");
+  OneEmail one(raw, raw_len, from_domain, domain_len, key, key_len, key_type, external_input_null);
+  std::vector<uint32_t> hids, bids, cap_off{0}, str_off{0};
+  std::vector<uint8_t> blob;
+  for (int side = 0; side < 2; side++) {
+    const zke_regex_part* parts = side ? body_parts : header_parts;
+    const uint32_t np = side ? n_body_parts : n_header_parts;
+    for (uint32_t k = 0; k < np; k++) {
+      const zke_regex_part& p = parts[k];
+      if ((p.fwd_len && !p.fwd) || (p.bwd_len && !p.bwd) || (p.n_captures && (!p.captures || !p.capture_lens)))
+        return fail(e, ZKE_E_ARG, "zke_verify_email_with_regex: null pointer in a part");
+      uint32_t id = 0;
+      if (int r = zke_dfa_register(e, p.fwd, p.fwd_len, p.bwd, p.bwd_len, &id)) return r;     // the same pair gets the same id
+      (side ? bids : hids).push_back(id);
+      for (uint32_t c = 0; c < p.n_captures; c++) {
+        if (p.capture_lens[c] && !p.captures[c]) return fail(e, ZKE_E_ARG, "zke_verify_email_with_regex: null capture");
+        blob.insert(blob.end(), p.captures[c], p.captures[c] + p.capture_lens[c]);
+        str_off.push_back((uint32_t)blob.size());
+      }
+      cap_off.push_back((uint32_t)str_off.size() - 1);
+    }
+  }
+  if (blob.empty()) blob.push_back(0);
+  zke_batch& b = one.b;
+  b.with_regex = 1;
+  b.n_header_parts = n_header_parts; b.n_body_parts = n_body_parts;
+  b.header_part_ids = hids.data(); b.body_part_ids = bids.data();
+  b.cap_off = cap_off.data(); b.cap_str_off = str_off.data(); b.cap_blob = blob.data();
   return zke_verify_batch(e, &b, out, nullptr);
 }
 

@@ -64,8 +64,15 @@ def load_library(path: Optional[str] = None):
     lib.zke_get_timings.restype = C.c_int
     lib.zke_set_timing.argtypes = [vp, C.c_int]
     lib.zke_set_timing.restype = C.c_int
-    lib.zke_verify_email.argtypes = [vp, vp, C.c_size_t, C.c_char_p, C.c_size_t, vp, C.c_size_t, C.c_uint32, vp]
+    lib.zke_verify_email.argtypes = [vp, vp, C.c_size_t, C.c_char_p, C.c_size_t, vp, C.c_size_t, C.c_uint32, C.c_uint32, vp]
     lib.zke_verify_email.restype = C.c_int
+    lib.zke_verify_email_with_regex.argtypes = [vp, vp, C.c_size_t, C.c_char_p, C.c_size_t, vp, C.c_size_t, C.c_uint32, C.c_uint32,
+                                                C.POINTER(A.zke_regex_part), C.c_uint32, C.POINTER(A.zke_regex_part), C.c_uint32, vp]
+    lib.zke_verify_email_with_regex.restype = C.c_int
+    lib.zke_engine_reserve.argtypes = [vp, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32]
+    lib.zke_engine_reserve.restype = C.c_int
+    lib.zke_get_slot_timings.argtypes = [vp, C.c_uint32, C.POINTER(A.zke_timings)]
+    lib.zke_get_slot_timings.restype = C.c_int
     lib.zke_sha256_batch.argtypes = [vp, vp, vp, C.c_uint32, vp]
     lib.zke_sha256_batch.restype = C.c_int
     lib.zke_sha256_batch_device.argtypes = [vp, vp, vp, C.c_uint32, vp, vp]
@@ -87,7 +94,7 @@ EXPORTED_SYMBOLS = [
     "zke_engine_create", "zke_engine_destroy", "zke_last_error", "zke_dfa_register", "zke_verify_batch",
     "zke_verify_batch_device", "zke_engine_sync", "zke_get_timings", "zke_set_timing", "zke_verify_email",
     "zke_sha256_batch", "zke_sha256_batch_device", "zke_rsa_modexp_batch", "zke_version", "zke_device_available",
-    "zke_ed25519_verify_batch",
+    "zke_ed25519_verify_batch", "zke_engine_reserve", "zke_get_slot_timings", "zke_verify_email_with_regex",
 ]
 
 
@@ -149,8 +156,18 @@ class Engine:
         self._check(self.lib.zke_verify_batch_device(self.h, C.byref(cbatch), raw_total, domain_total, key_total,
                                                      out_dev_ptr, stream), "zke_verify_batch_device")
 
+    def reserve(self, max_n: int, max_raw_total: int, slots: int = 1, max_regex_parts: int = 0):
+        """Size `slots` submission slots for batches of up to max_n e-mails / max_raw_total raw bytes: nothing is
+        allocated in the submit path afterwards; `slots` batches can be in flight (zke_engine_reserve)."""
+        self._check(self.lib.zke_engine_reserve(self.h, max_n, max_raw_total, slots, max_regex_parts), "zke_engine_reserve")
+
     def sync(self):
         self._check(self.lib.zke_engine_sync(self.h), "zke_engine_sync")
+
+    def slot_timings(self, slot: int) -> dict:
+        t = A.zke_timings()
+        self._check(self.lib.zke_get_slot_timings(self.h, slot, C.byref(t)), "zke_get_slot_timings")
+        return {k: getattr(t, k) for k, _ in A.zke_timings._fields_}
 
     def set_timing(self, on: bool):
         self._check(self.lib.zke_set_timing(self.h, 1 if on else 0), "zke_set_timing")
@@ -213,16 +230,53 @@ class Engine:
             caps.append([list(p.captures or []) for p in list(h2) + list(b2)])
         return PackedBatch([i.email for i in inputs], hids, bids, caps, with_regex=True)
 
+    def _email_args(self, email: Email):
+        raw = np.frombuffer(email.raw_email or b"\0", np.uint8)
+        key = np.frombuffer(email.public_key.key or b"\0", np.uint8)
+        dom = email.from_domain.encode("utf-8")
+        ext = 1 if any(x.value is None for x in email.external_inputs) else 0
+        return (raw, key), [raw.ctypes.data, len(email.raw_email), dom, len(dom), key.ctypes.data, len(email.public_key.key),
+                            A.key_type_code(email.public_key.key_type), ext]
+
     def verify_email(self, email: Email) -> EmailVerifierOutput:
-        """core/src/circuits.rs:9-29."""
-        r = self.verify_batch(PackedBatch([email]))[0]
+        """core/src/circuits.rs:9-29, through the single-e-mail C entry point zke_verify_email."""
+        keep, args = self._email_args(email)
+        out = np.zeros(1, dtype=A.RESULT_DTYPE)
+        self._check(self.lib.zke_verify_email(self.h, *args, out.ctypes.data), "zke_verify_email")
+        r = out[0]
         if r["status"] != A.ZKE_OK:
             raise VerifyPanic(int(r["status"]), int(r["detail"]))
         return _email_output(email, r)
 
     def verify_email_with_regex(self, inp: EmailWithRegex) -> EmailWithRegexVerifierOutput:
-        """core/src/circuits.rs:31-68."""
-        r = self.verify_batch(self.pack_with_regex([inp]))[0]
+        """core/src/circuits.rs:31-68, through the single-e-mail C entry point zke_verify_email_with_regex."""
+        keep, args = self._email_args(inp.email)
+        hold = []
+
+        def parts_array(parts):
+            parts = list(parts or [])
+            arr = (A.zke_regex_part * max(len(parts), 1))()
+            for k, p in enumerate(parts):
+                f = np.frombuffer(p.verify_re.fwd or b"\0", np.uint8)
+                b = np.frombuffer(p.verify_re.bwd or b"\0", np.uint8)
+                caps = [c.encode("utf-8") if isinstance(c, str) else bytes(c) for c in (p.captures or [])]
+                bufs = [np.frombuffer(c or b"\0", np.uint8) for c in caps]
+                ptrs = (C.c_void_p * max(len(caps), 1))(*[x.ctypes.data for x in bufs])
+                lens = (C.c_size_t * max(len(caps), 1))(*[len(c) for c in caps])
+                hold.extend([f, b, bufs, ptrs, lens])
+                arr[k].fwd, arr[k].fwd_len = f.ctypes.data, len(p.verify_re.fwd)
+                arr[k].bwd, arr[k].bwd_len = b.ctypes.data, len(p.verify_re.bwd)
+                arr[k].n_captures = len(caps)
+                arr[k].captures = C.cast(ptrs, C.POINTER(C.c_void_p))
+                arr[k].capture_lens = C.cast(lens, C.POINTER(C.c_size_t))
+            return arr, len(parts)
+
+        ha, nh = parts_array(inp.regex_info.header_parts)
+        ba, nb = parts_array(inp.regex_info.body_parts)
+        out = np.zeros(1, dtype=A.RESULT_DTYPE)
+        self._check(self.lib.zke_verify_email_with_regex(self.h, *args, ha, nh, ba, nb, out.ctypes.data),
+                    "zke_verify_email_with_regex")
+        r = out[0]
         if r["status"] != A.ZKE_OK:
             raise VerifyPanic(int(r["status"]), int(r["detail"]))
         return EmailWithRegexVerifierOutput(_email_output(inp.email, r), regex_matches_of(inp))
