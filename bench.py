@@ -116,8 +116,11 @@ def main():
     if world != args.gpus and world > 1:
         args.gpus = world
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    # HIP multiplexes streams onto 4 hardware queues by default; the batches in flight need one each
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, min(args.streams, 20))))
+    # HIP multiplexes streams onto 4 hardware queues by default.  Every slot stream needs a queue of its own, and the
+    # null stream and the runtime's own queues come out of the same pool: with exactly S queues two slots end up
+    # sharing one (measured: 20 slots on 20 queues 18.8 M e-mails/s, on 24 queues 23.1 M; more queues than streams
+    # change nothing, but idle queues beyond ~32 cost: 40 mapped queues 11.9 M).  profiles/r02_hw_queues.txt
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, min(args.streams, 28) + 4)))
 
     import torch
     import torch.distributed as dist
@@ -196,14 +199,28 @@ def main():
     base_ptr = results_all.data_ptr()
     counter = [0]
 
+    # experiment knobs (not the measured configuration): caller-provided torch streams instead of the slots' own;
+    # S engines with one slot each instead of one engine with S slots
+    x_torch_streams = os.environ.get("ZKE_BENCH_TORCH_STREAMS") == "1"
+    x_multi_engine = os.environ.get("ZKE_BENCH_MULTI_ENGINE") == "1"
+    tstreams = [torch.cuda.Stream(device=dev) for _ in range(S)] if x_torch_streams else None
+    xengines = None
+    if x_multi_engine:
+        xengines = [z.Engine(device=local_rank) for _ in range(S)]
+        for xe in xengines:
+            xe.reserve(n, totals[0], 1, P)
+
     def step():
         # slot i % S (the engine takes its slots round-robin) on that slot's own stream; record slice i % n_slices
         i = counter[0]
         counter[0] += 1
-        eng.verify_batch_device(cb, totals[0], totals[1], totals[2], base_ptr + (i % n_slices) * rec_bytes, 0)
+        st = tstreams[i % S].cuda_stream if tstreams else 0
+        (xengines[i % S] if xengines else eng).verify_batch_device(cb, totals[0], totals[1], totals[2], base_ptr + (i % n_slices) * rec_bytes, st)
 
     def fence():
         eng.sync()
+        for xe in (xengines or []):
+            xe.sync()
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -219,6 +236,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_submitted = time.perf_counter() - t0            # the host side of the timed region: K submissions
     if use_dist:
         eng.sync()                                    # every batch of this rank is done
         torch.cuda.synchronize()
@@ -346,6 +364,7 @@ def main():
         "roofline": roof,
         "kernels_us_in_flight": {k: round(v, 2) for k, v in kern_flight.items()},
         "kernels_us_alone": {k: round(v, 2) for k, v in kern_alone.items()} if kern_alone else None,
+        "host_submit_ms": round(t_submitted * 1e3, 3),
         "sha256_saturated": sha_sat,
         "workload_gen_s": round(gen_s, 2),
     }

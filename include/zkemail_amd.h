@@ -173,6 +173,10 @@ typedef struct zke_debug_out {
   uint8_t* clean_body;   size_t clean_body_stride;    /* after remove_quoted_printable_soft_breaks (email.rs:61-86) */
   uint8_t* em;           size_t em_stride;            /* sig^e mod n, big-endian, k bytes */
   uint32_t* canon_body_full_len;                      /* [n] canonical body length before l= */
+  uint32_t* rsa_route;                                /* [n] which RSA routine takes the e-mail's signatures: 4 four lanes per signature,
+                                                         8 eight lanes (the key's constants were cached); else one signature per
+                                                         wave and why: 0x100 no lane-group kernel for this size in the launch,
+                                                         0x200 key not cached yet, 0x400 cache slot taken, 0x800 not eligible */
 } zke_debug_out;
 
 typedef struct zke_options {

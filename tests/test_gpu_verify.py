@@ -234,10 +234,68 @@ def test_rsa_quad_kernel_variant_parity():
         t.test_mixed_key_types_one_batch(eng, orc)
         t.test_signature_rounds(eng, orc)
         t.test_limits_and_large_header_blocks_parity(eng, orc)
+        t.test_rsa_routing_through_the_key_cache(eng, orc)
         print("rsa quad ok")
     """)
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ZKE_RSA_QUAD="1"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "rsa quad ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_rsa_routing_through_the_key_cache(engine, oracle):
+    """The front end routes a signature to the lane-group RSA routine when its key's Montgomery constants are cached (the
+    modulus compared limb by limb), else to the one-signature-per-wave routine, which fills the cache.  Fresh keys: the first
+    batch takes the wave routine (route 0); the same batch again takes four lanes per signature (RSA-1024 / 2048) or eight
+    (RSA-3072 / 4096) where that kernel is part of the launch — records and EM blocks identical both times and to the oracle.
+    Signatures rsa 0.9.6 rejects before the arithmetic (s >= n, wrong length) are rejected by either routine."""
+    import subprocess, tempfile
+    forced = os.environ.get("ZKE_RSA_QUAD") == "1"          # else the lane-group kernels join only large batches: parity only
+    fresh = []
+    with tempfile.TemporaryDirectory() as td:
+        for bits in (1024, 2048, 3072, 4096):
+            pem = os.path.join(td, f"k{bits}.pem")
+            subprocess.run(["openssl", "genrsa", "-out", pem, str(bits)], check=True, capture_output=True)
+            txt = subprocess.run(["openssl", "rsa", "-in", pem, "-noout", "-text"], check=True, capture_output=True, text=True).stdout
+            def field(name):
+                seg = txt.split(name + ":")[1]
+                hexs = ""
+                for ln in seg.splitlines()[1:]:
+                    if not ln.startswith("    "):
+                        break
+                    hexs += ln.strip().replace(":", "")
+                return int(hexs, 16)
+            n_, d_, p_, q_ = field("modulus"), field("privateExponent"), field("prime1"), field("prime2")
+            fresh.append(synth.RsaKey(f"fresh{bits}", bits, n_, 65537, d_, p_, q_, synth.pkcs1_pub_der(n_, 65537)))
+    rng = np.random.default_rng(77)
+    emails, inter = [], []
+    for i in range(40):
+        key = fresh[i % 4]
+        body = synth.ascii_body(rng, 700 + 13 * i)
+        raw, it = synth.sign_email(synth.std_headers(rng, i, "example.com"), body, key, SignSpec(domain="example.com"))
+        if i in (9, 10, 11, 12):            # b= replaced by n (s >= n) or by one byte less than the modulus
+            import base64
+            a = raw.find(b" b=") + 3
+            z = raw.find(b"\r\nReceived", a)
+            bad = key.n.to_bytes(key.k, "big") if i < 11 else it["sig"][1:]
+            raw = raw[:a] + base64.b64encode(bad) + raw[z:]
+            it = None
+        emails.append(A.Email("example.com", raw, A.PublicKey(key.pkcs1_der)))
+        inter.append(it)
+    got1, exp, d1, d2 = run_both(engine, oracle, emails)
+    got2, _, d3, _ = run_both(engine, oracle, emails)
+    assert_records_equal(got1, exp, None, "routing, first batch")
+    assert_records_equal(got2, exp, None, "routing, second batch")
+    assert ((d1.rsa_route & 12) == 0).all(), d1.rsa_route          # fresh keys: nothing cached (0x200), or no lane-group kernel (0x800)
+    for i in range(40):
+        bits = fresh[i % 4].bits
+        want = (4 if bits <= 2048 else 8) if forced else int(d3.rsa_route[i])
+        assert int(d3.rsa_route[i]) == want, (i, bits, [hex(int(x)) for x in d1.rsa_route[:4]], [hex(int(x)) for x in d3.rsa_route[:8]])
+        if inter[i] is None:
+            assert int(got2[i]["status"]) == A.ZKE_DKIM_NOT_PASS and int(got2[i]["detail"]) == A.D_SIG_MISMATCH, i
+            assert not d1.em[i].any() and not d3.em[i].any(), i
+        else:
+            assert int(got2[i]["status"]) == A.ZKE_OK, (i, int(got2[i]["status"]), int(got2[i]["detail"]))
+            k = len(inter[i]["em"])
+            assert bytes(d1.em[i, :k]) == inter[i]["em"] == bytes(d3.em[i, :k]) == bytes(d2.em[i, :k]), i
 
 
 def test_limits_and_large_header_blocks_parity(engine, oracle):

@@ -129,6 +129,7 @@ class zke_debug_out(C.Structure):
         ("clean_body", C.c_void_p), ("clean_body_stride", C.c_size_t),
         ("em", C.c_void_p), ("em_stride", C.c_size_t),
         ("canon_body_full_len", C.c_void_p),
+        ("rsa_route", C.c_void_p),
     ]
 
 
@@ -293,10 +294,12 @@ class DebugBuffers:
         self.clean_body = np.zeros((max(n, 1), body_stride), np.uint8)
         self.em = np.zeros((max(n, 1), em_stride), np.uint8)
         self.full_len = np.zeros(max(n, 1), np.uint32)
+        self.rsa_route = np.zeros(max(n, 1), np.uint32)
         d = zke_debug_out()
         d.canon_header = self.canon_header.ctypes.data; d.canon_header_stride = hdr_stride
         d.canon_body = self.canon_body.ctypes.data; d.canon_body_stride = body_stride
         d.clean_body = self.clean_body.ctypes.data; d.clean_body_stride = body_stride
         d.em = self.em.ctypes.data; d.em_stride = em_stride
         d.canon_body_full_len = self.full_len.ctypes.data
+        d.rsa_route = self.rsa_route.ctypes.data
         self.c = d

@@ -313,74 +313,78 @@ __global__ __launch_bounds__(64) void canon_body_kernel(CanonArgs A) {
 // ---- verdict of one signature round, by the wave that ran the e-mail's RSA job -----------------------
 struct FinArgs { BatchDev b; uint32_t round, max_rounds; uint32_t* pending; uint32_t debug_skip_rsa; };   // debug_skip_rsa: ablation experiments only
 
-__device__ __forceinline__ void verdict_wave(const FinArgs& A, uint32_t i, bool rsa_ok, int lane) {
+// The verdict of e-mail i, by ONE LANE (64 e-mails per wave at once: the loads of an e-mail's state are a dependent
+// chain of a microsecond or so, which a wave walking its e-mails one after the other would pay 64 times over).
+// rsa_ok: the RSA outcome (EM's shape and digest both fit); ed_ok / ed_key_bad: the Ed25519 stage's.
+__device__ __forceinline__ void verdict_lane(const FinArgs& A, uint32_t i, bool rsa_ok, bool ed_ok, bool ed_key_bad) {
   const BatchDev& B = A.b;
   EmailMeta* M = B.meta + i;
   zke_result* R = B.results + i;
   const uint32_t state = M->state;
   uint32_t status, detail;
-  if (M->ed_key_bad) {
+  if (ed_key_bad) {
     // DkimPublicKey::try_from_bytes (email.rs:28-29) fails before any signature is looked at: nothing of the
     // DKIM scan may show in the record
     status = ZKE_KEY_DECODE_FAIL; detail = ZKE_D_KEY_ED25519_POINT;
-    if (lane == 0) {
-      M->state = ST_FINAL; M->status = status; M->detail = detail;
-      R->sig_index = 0; R->flags = 0; R->canon_header_len = 0; R->canon_body_len = 0;
-    }
-    if (lane < 16) { ((uint32_t*)R->body_hash)[lane & 7] = 0; if (lane >= 8) ((uint32_t*)R->header_hash)[lane & 7] = 0; }
+    M->state = ST_FINAL; M->status = status; M->detail = detail;
+    R->sig_index = 0; R->flags = 0; R->canon_header_len = 0; R->canon_body_len = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { ((uint32_t*)R->body_hash)[k] = 0; ((uint32_t*)R->header_hash)[k] = 0; }
   } else if (state == ST_FINAL) {
     status = M->status; detail = M->detail;
   } else {
     // cfdkim verify_email_header: bh compare (as base64 strings), b= decode, RSA verify
     uint32_t err = 0;
     {
-      // lane t produces base64 character t of the body hash (32 bytes -> 44 chars, SHA-1: 20 -> 28) and compares it with bh=
-      const uint32_t hl = (M->flags & ZKE_F_SHA1) ? 20u : 32u, nch = (M->flags & ZKE_F_SHA1) ? 28u : 44u;
-      bool bad = false;
-      if ((uint32_t)lane < nch) {
-        const uint8_t* h = R->body_hash;
-        const uint32_t g = lane >> 2, k = lane & 3;
+      // base64 of the body hash (32 bytes -> 44 chars, SHA-1: 20 -> 28), three bytes / four characters at a time, against bh=
+      const bool sha1 = (M->flags & ZKE_F_SHA1) != 0;
+      const uint32_t hl = sha1 ? 20u : 32u, nch = sha1 ? 28u : 44u;
+      const uint8_t* h = R->body_hash;
+      bool bad = M->bh_len != nch;
+      auto b64c = [](uint32_t six) -> uint32_t {
+        return six < 26 ? 'A' + six : (six < 52 ? 'a' + (six - 26) : (six < 62 ? '0' + (six - 52) : (six == 62 ? '+' : '/')));
+      };
+      for (uint32_t g = 0; g < nch / 4; g++) {
         const uint32_t b0 = h[3 * g], b1 = (3 * g + 1 < hl) ? h[3 * g + 1] : 0u, b2 = (3 * g + 2 < hl) ? h[3 * g + 2] : 0u;
         const uint32_t v = (b0 << 16) | (b1 << 8) | b2;
-        const uint32_t six = (v >> (18 - 6 * k)) & 63;
-        uint32_t ch = six < 26 ? 'A' + six : (six < 52 ? 'a' + (six - 26) : (six < 62 ? '0' + (six - 52) : (six == 62 ? '+' : '/')));
-        if ((uint32_t)lane == nch - 1) ch = '=';
-        bad = M->bh[lane] != (uint8_t)ch;
+        uint32_t c3 = b64c(v & 63);
+        if (4 * g + 3 == nch - 1) c3 = '=';                  // 32 and 20 are 2 mod 3: one pad character, the last
+        const uint32_t want = b64c(v >> 18) | (b64c((v >> 12) & 63) << 8) | (b64c((v >> 6) & 63) << 16) | (c3 << 24);
+        const uint32_t have = (uint32_t)M->bh[4 * g] | ((uint32_t)M->bh[4 * g + 1] << 8) | ((uint32_t)M->bh[4 * g + 2] << 16) | ((uint32_t)M->bh[4 * g + 3] << 24);
+        bad = bad || want != have;
       }
-      if (__ballot(bad) != 0 || M->bh_len != nch) err = ZKE_D_BODY_HASH_MISMATCH;
+      if (bad) err = ZKE_D_BODY_HASH_MISMATCH;
     }
     bool unsupported_here = false;
     if (!err && !M->sig_b64_ok) err = ZKE_D_SIG_B64;
     if (!err && M->even_modulus) { err = ZKE_D_U_EVEN_MODULUS; unsupported_here = true; }
-    const bool sig_ok = (M->flags & ZKE_F_ED25519) ? (M->ed_ok != 0) : rsa_ok;
+    const bool sig_ok = (M->flags & ZKE_F_ED25519) ? ed_ok : rsa_ok;
     if (!err && !sig_ok) err = ZKE_D_SIG_MISMATCH;
     if (!err) {
       status = ZKE_OK; detail = 0;
-      if (lane == 0) R->sig_index = M->cand_sig_index;
+      R->sig_index = M->cand_sig_index;
     } else if (M->cand_total > A.round + 1) {
       if (A.round + 1 < A.max_rounds) {
-        if (lane == 0) {
-          if (unsupported_here) M->unsupported = err;
-          M->state = ST_PENDING; M->cand_err = err; R->status = ZKE_DKIM_NOT_PASS; R->detail = err;
-          atomicAdd(A.pending, 1u);
-        }
+        if (unsupported_here) M->unsupported = err;
+        M->state = ST_PENDING; M->cand_err = err; R->status = ZKE_DKIM_NOT_PASS; R->detail = err;
+        atomicAdd(A.pending, 1u);
         return;
       }
       status = ZKE_UNSUPPORTED; detail = ZKE_D_U_TOO_MANY_SIGS;
-      if (lane == 0) R->sig_index = M->last_touched_sig;
+      R->sig_index = M->last_touched_sig;
     } else {
-      if (lane == 0) R->sig_index = M->last_touched_sig;
+      R->sig_index = M->last_touched_sig;
       const uint32_t uns = unsupported_here ? err : M->unsupported;
       if (uns) { status = ZKE_UNSUPPORTED; detail = uns; }
       else { status = ZKE_DKIM_NOT_PASS; detail = M->post_err ? M->post_err : err; }
     }
-    if (lane == 0) { M->state = ST_FINAL; M->status = status; M->detail = detail; }
+    M->state = ST_FINAL; M->status = status; M->detail = detail;
   }
   if (status == ZKE_OK && B.ext_null && B.ext_null[i]) status = ZKE_EXTERNAL_INPUT_NULL;   // circuits.rs:24
-  if (lane == 0) { R->status = status; R->detail = detail; }
-  if (status != ZKE_OK && status != ZKE_EXTERNAL_INPUT_NULL && lane < 16) {
-    ((uint32_t*)R->from_domain_hash)[lane & 7] = 0;          // lanes 0-7
-    if (lane >= 8) ((uint32_t*)R->public_key_hash)[lane & 7] = 0;
+  R->status = status; R->detail = detail;
+  if (status != ZKE_OK && status != ZKE_EXTERNAL_INPUT_NULL) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) { ((uint32_t*)R->from_domain_hash)[k] = 0; ((uint32_t*)R->public_key_hash)[k] = 0; }
   }
 }
 

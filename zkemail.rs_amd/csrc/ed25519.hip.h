@@ -453,29 +453,4 @@ __global__ __launch_bounds__(64) void ed25519_verify_kernel(const uint8_t* keys,
   out[i] = ed25519_verify_lane(keys + (size_t)i * 32, msgs + (size_t)i * msg_len, msg_len, sigs + (size_t)i * 64, true);
 }
 
-// Pipeline stage between the SHA launch and the RSA/verdict launch: lane i looks at e-mail i.
-//   round 0: every e-mail that carries a 32-byte Ed25519 key gets the curve-point check VerifyingKey::from_bytes
-//            makes (core/src/email.rs:28-29 runs it before any signature is read) -> EmailMeta::ed_key_bad;
-//   any round: a candidate signed a=ed25519-sha256 is verified against the SHA-256 header hash the SHA launch
-//            left in the result record -> EmailMeta::ed_ok, which verdict_wave reads in place of the RSA outcome.
-// Waves without an Ed25519 e-mail leave after one byte load per lane.
-struct EdArgs { BatchDev b; uint32_t round; };
-
-__global__ __launch_bounds__(64) void ed25519_email_kernel(EdArgs A) {
-  const BatchDev& B = A.b;
-  const uint32_t i = blockIdx.x * 64 + threadIdx.x;
-  if (i >= B.n) return;
-  if (B.key_type[i] != ZKE_KEY_ED25519) return;
-  EmailMeta* M = B.meta + i;
-  if (M->key_ok != 2) return;                      // parse failed before key decode, or the key is not 32 bytes
-  const bool cand = M->state == ST_CAND && (M->flags & ZKE_F_ED25519);
-  if (A.round > 0 && !cand) return;                // the key was checked in round 0
-  const RsaJob* J = B.rsa + i;
-  const zke_result* R = B.results + i;
-  const bool have_sig = cand && J->sig_len == 64;  // a b= of any other length cannot be an Ed25519 signature
-  const uint32_t r = ed25519_verify_lane(B.key + B.key_off[i], R->header_hash, 32, J->sig + (512 - 64), have_sig);
-  if (r == 0) M->ed_key_bad = 1;
-  M->ed_ok = (r == 2) ? 1u : 0u;
-}
-
 }  // namespace zke

@@ -22,7 +22,9 @@
 #include "regex.hip.h"
 #include "rsa_kernel.hip.h"
 #include "rsa_quad.hip.h"
+#include "fused.hip.h"
 #include "ed25519.hip.h"
+#include "verdict.hip.h"
 
 using namespace zke;
 
@@ -101,8 +103,9 @@ struct zke_engine {
   size_t dfa_wave_lds_attr = 0;
   uint64_t batch_key_total = 0;     // key bytes of the batch being run: > 272 per e-mail -> some modulus is above 2048 bits
   int rsa_quad = -1;                // four-lanes-per-signature RSA kernel (rsa_quad.hip.h): -1 by batch size, 0 never, 1 always (ZKE_RSA_QUAD)
-  uint32_t rsa_quad_min = 2048;     // -1: batches of at least this many e-mails (ZKE_RSA_QUAD_MIN)
-  uint32_t rsa_oct_min = 1024;      // ... for the eight-lane form of moduli above 2048 bits (ZKE_RSA_OCT_MIN)
+  uint32_t rsa_quad_min = 0;        // -1: batches of at least this many e-mails (ZKE_RSA_QUAD_MIN).  0 since the modexp runs beside
+                                    // SHA-256 (fused.hip.h): its longer chain no longer sits behind the hashes of a small batch
+  uint32_t rsa_oct_min = 0;         // ... for the eight-lane form of moduli above 2048 bits (ZKE_RSA_OCT_MIN)
   int sha_pair = -1;                // two-wave SHA-256 kernel: -1 by launch size, 0 never, 1 always (ZKE_SHA_PAIR)
   bool wave_parse = true;           // front end: one e-mail per wavefront (parse.hip.h); ZKE_LANE_PARSE=1 selects the
                                     // one-e-mail-per-lane variant (front.hip.h), see DESIGN.md §3
@@ -112,6 +115,7 @@ struct zke_engine {
   uint32_t debug_parse_stop = 0;    // ZKE_DEBUG_PARSE_STOP: timing experiments (results are then meaningless)
   uint32_t max_sig_rounds = 4;      // host mode: upper bound, rounds are added only while e-mails are pending
   uint32_t device_mode_rounds = 1;  // device mode: fixed (no read-back)
+  uint32_t key_cache_replicas = 1;  // ZKE_KEY_CACHE_REPLICAS (experiment): slot k uses copy k % replicas of the key cache
 };
 
 namespace {
@@ -177,7 +181,11 @@ int set_sha_attrs_any(zke_engine* e) {
 
 Slot* new_slot(zke_engine* e) {
   Slot* w = new Slot();
-  bool ok = hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) == hipSuccess &&
+  if (const char* xd = getenv("ZKE_X_DUMMY_STREAMS")) {        // experiment: idle streams created in front of each slot's stream (leaked)
+    for (int k = 0; k < atoi(xd); k++) { hipStream_t d; (void)hipStreamCreateWithFlags(&d, hipStreamNonBlocking); }
+  }
+  const char* sp = getenv("ZKE_STREAM_PRIO");     // experiment: create the slot streams with an explicit priority
+  bool ok = (sp ? hipStreamCreateWithPriority(&w->stream, hipStreamNonBlocking, atoi(sp)) : hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking)) == hipSuccess &&
             hipEventCreateWithFlags(&w->done, hipEventDisableTiming) == hipSuccess;
   for (auto& ev : w->ev) ok = ok && hipEventCreate(&ev) == hipSuccess;
   if (!ok) { e->err = "slot stream / event creation"; delete w; return nullptr; }
@@ -193,33 +201,73 @@ void free_slot(Slot* w) {
   delete w;
 }
 
-// key_hash_base: &results[0].public_key_hash (same stride as hash_base) or nullptr = no key cache;
-// fin.b.results != nullptr: the kernel also writes each e-mail's verdict
-int launch_rsa(zke_engine* e, const RsaJob* jobs, uint32_t n, const uint8_t* hash_base, size_t hash_stride,
-               uint32_t* ok, uint8_t* em, hipStream_t s, bool any_big, const uint8_t* key_hash_base, const FinArgs& fin) {
-  if (n == 0) return 0;
-  const uint32_t grid = n;
-  KeyCacheEntry* cache = key_hash_base ? e->key_cache.as<KeyCacheEntry>() : nullptr;
-  // Moduli of up to 2048 bits with e = 65537 and cached key constants go to the four-lanes-per-signature kernel
-  // (rsa_quad.hip.h); the one-signature-per-wave kernel runs first, fills the key cache, marks those jobs and does the rest.
-  // Its waves carry 16 signatures through one ~95 k-instruction chain (alone: 210 us per launch instead of 52), so it pays
-  // when a launch has enough of them to fill the chip: 8 192 e-mails per batch +27 %, 4 096 +19 %, 1 024 -16 %.
-  // The eight-lane form replaces a much slower kernel (46 k instructions per RSA-4096 signature) and pays from 1 024 per batch
-  // (+17 %; 2 048: +50 %; 512: -28 %).  Bit 0: four lanes (<= 2048 bits), bit 1: eight lanes (2049..4096 bits).
-  uint32_t quad = 0;
-  if (cache && fin.b.results) {
-    if (e->rsa_quad > 0 || (e->rsa_quad < 0 && n >= e->rsa_quad_min)) quad |= 1u;
-    // any_big (the caller's hint: the batch's keys average more than an RSA-2048 key) gates the eight-lane launch; without it
-    // the pre-pass keeps large moduli for itself, so the two always agree
-    if (any_big && (e->rsa_quad > 0 || (e->rsa_quad < 0 && n >= e->rsa_oct_min))) quad |= 2u;
-  }
-  hipLaunchKernelGGL(rsa_verify_kernel, dim3(grid), dim3(64), 0, s, jobs, n, hash_base, hash_stride, ok, em, cache, key_hash_base, fin, quad);
-  if (quad & 1u)
-    hipLaunchKernelGGL(rsa_group_kernel<4>, dim3((n + 15) / 16), dim3(64), 0, s, jobs, n, hash_base, hash_stride, ok, em, cache, key_hash_base, fin);
-  if (quad & 2u)
-    hipLaunchKernelGGL(rsa_group_kernel<8>, dim3((n + 7) / 8), dim3(64), 0, s, jobs, n, hash_base, hash_stride, ok, em, cache, key_hash_base, fin);
+// Which lane-group RSA kernels take part in a batch of n e-mails.  Bit 0: four lanes per signature (moduli <= 2048 bits),
+// bit 1: eight lanes (2049..4096 bits; any_big = the caller's hint that the batch's keys average more than an RSA-2048 key).
+// The front end routes signatures by this mask and the hash / modexp launch gets the matching workgroups: the same value
+// must go to both.  -1 = by batch size (ZKE_RSA_QUAD_MIN / ZKE_RSA_OCT_MIN), 0 never, 1 always (ZKE_RSA_QUAD).
+uint32_t rsa_route_mask(const zke_engine* e, uint32_t n, bool any_big) {
+  if (!e->key_cache.p) return 0;
+  uint32_t m = 0;
+  if (e->rsa_quad > 0 || (e->rsa_quad < 0 && n >= e->rsa_quad_min)) m |= 1u;
+  if (any_big && (e->rsa_quad > 0 || (e->rsa_quad < 0 && n >= e->rsa_oct_min))) m |= 2u;
+  return m;
+}
+
+template <int T>
+int launch_stage_t(zke_engine* e, const StageArgs& A, hipStream_t s) {
+  const uint32_t grid = A.g_sha + A.g_wave + A.g_quad + A.g_oct;
+  if (!grid) return 0;
+  hipLaunchKernelGGL(hash_modexp_kernel<T>, dim3(grid), dim3(128), sha256_pair_lds_bytes<T>(), s, A);
   HIPCHK(e, hipGetLastError());
   return 0;
+}
+int launch_stage_any(zke_engine* e, const StageArgs& A, hipStream_t s) {
+  switch (e->sha_tile) {
+    case 64: return launch_stage_t<64>(e, A, s);
+    case 256: return launch_stage_t<256>(e, A, s);
+    case 512: return launch_stage_t<512>(e, A, s);
+    default: return launch_stage_t<SHA_TILE>(e, A, s);
+  }
+}
+
+// The hash / modexp stage of a batch (fused.hip.h): SHA-256 of the 4 * n_pad messages and the RSA operation of the n jobs.
+// Launches of up to SHA_PAIR_MAX_GROUPS SHA-256 groups (every BASELINE-sized batch) are ONE kernel; beyond that the chip
+// is full of SHA-256 waves anyway: sha256_batch_kernel first, then the RSA roles as a launch of their own.
+constexpr uint32_t WAVE_ROLE_MAX_GROUPS = 128;     // 256 waves walk the job list: a batch of 1 024 uncached keys takes four rounds of them
+int launch_hash_modexp(zke_engine* e, const ShaJob* sha, uint32_t n_sha, const RsaJob* rsa, uint32_t n, EmailMeta* meta,
+                       uint8_t* em_out, uint32_t route_mask, const uint32_t* wave_count, const uint32_t* wave_list, hipStream_t s) {
+  StageArgs A{};
+  A.sha = sha; A.n_sha = n_sha; A.rsa = rsa; A.n = n; A.meta = meta;
+  A.cache = e->key_cache.as<KeyCacheEntry>();
+  A.em_out = em_out;
+  A.wave_count = wave_count; A.wave_list = wave_list;
+  A.g_wave = wave_list ? std::min<uint32_t>((n + 1) / 2, WAVE_ROLE_MAX_GROUPS) : (n + 1) / 2;
+  A.g_quad = (route_mask & 1u) ? (n + 31) / 32 : 0;
+  A.g_oct = (route_mask & 2u) ? (n + 15) / 16 : 0;
+  A.debug_skip_rsa = e->debug_skip_rsa;
+  const uint32_t groups = (n_sha + 63) / 64;
+  if (e->sha_pair == 1 || (e->sha_pair < 0 && groups <= SHA_PAIR_MAX_GROUPS)) {
+    A.g_sha = groups;
+    return launch_stage_any(e, A, s);
+  }
+  if (int r = launch_sha_any(e, sha, n_sha, s)) return r;
+  A.g_sha = 0;
+  return launch_stage_any(e, A, s);
+}
+
+template <int T>
+int set_stage_attr(zke_engine* e) {
+  HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&hash_modexp_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)sha256_pair_lds_bytes<T>()));
+  return 0;
+}
+int set_stage_attr_any(zke_engine* e) {
+  switch (e->sha_tile) {
+    case 64: return set_stage_attr<64>(e);
+    case 256: return set_stage_attr<256>(e);
+    case 512: return set_stage_attr<512>(e);
+    default: return set_stage_attr<SHA_TILE>(e);
+  }
 }
 
 }  // namespace
@@ -250,9 +298,10 @@ int zke_engine_create(const zke_options* opt, zke_engine** out) {
   e->slots.push_back(w0);
   e->stream = w0->stream;
   for (auto& ev : e->ev_h2d) if (hipEventCreate(&ev) != hipSuccess) { zke_engine_destroy(e); return ZKE_E_DEVICE; }
+  if (const char* kr = getenv("ZKE_KEY_CACHE_REPLICAS")) e->key_cache_replicas = std::max(1, std::min(64, atoi(kr)));
   if (!(opt && opt->reserved[3])) {      // reserved[3] != 0: no per-key cache (R^2 mod n recomputed per signature)
-    if (e->key_cache.ensure((size_t)KEY_CACHE_SLOTS * sizeof(KeyCacheEntry)) ||
-        hipMemset(e->key_cache.p, 0, (size_t)KEY_CACHE_SLOTS * sizeof(KeyCacheEntry)) != hipSuccess) {
+    const size_t kc_bytes = (size_t)e->key_cache_replicas * KEY_CACHE_SLOTS * sizeof(KeyCacheEntry);
+    if (e->key_cache.ensure(kc_bytes) || hipMemset(e->key_cache.p, 0, kc_bytes) != hipSuccess) {
       zke_engine_destroy(e);
       return ZKE_E_NOMEM;
     }
@@ -368,7 +417,6 @@ int zke_rsa_modexp_batch(zke_engine* e, const uint8_t* sig, const uint8_t* mod, 
   if (n == 0) return 0;
   HIPCHK(e, hipSetDevice(e->device));
   std::vector<RsaJob> jobs(n);
-  bool any_big = false;
   for (uint32_t i = 0; i < n; i++) {
     RsaJob& j = jobs[i];
     memset(&j, 0, sizeof j);
@@ -385,7 +433,6 @@ int zke_rsa_modexp_batch(zke_engine* e, const uint8_t* sig, const uint8_t* mod, 
     j.e = exp[i];
     j.sig_len = j.k;
     j.flags = RSA_F_ACTIVE;
-    any_big |= bits > 2048;
     ok[i] = (uint8_t)((m[bytes - 1] & 1) && bits >= 2 && memcmp(s, m, bytes) < 0);
   }
   DevBuf dj, dok, dem, dh;
@@ -398,7 +445,11 @@ int zke_rsa_modexp_batch(zke_engine* e, const uint8_t* sig, const uint8_t* mod, 
   hipError_t he = hipMemcpyAsync(dj.p, jobs.data(), jobs.size() * sizeof(RsaJob), hipMemcpyHostToDevice, e->stream);
   if (he == hipSuccess) he = hipMemsetAsync(dh.p, 0, (size_t)n * 32, e->stream);
   if (he == hipSuccess) he = hipMemsetAsync(dem.p, 0, (size_t)n * 512, e->stream);
-  if (he == hipSuccess) r = launch_rsa(e, dj.as<RsaJob>(), n, dh.as<uint8_t>(), 32, dok.as<uint32_t>(), dem.as<uint8_t>(), e->stream, any_big, nullptr, FinArgs{});
+  if (he == hipSuccess) {       // one signature per wave, no key cache, digest slots of zeros: only EM is of interest
+    hipLaunchKernelGGL(rsa_verify_kernel, dim3(n), dim3(64), 0, e->stream, dj.as<RsaJob>(), n, dh.as<uint8_t>(), (size_t)32,
+                       dok.as<uint32_t>(), dem.as<uint8_t>(), (KeyCacheEntry*)nullptr, (EmailMeta*)nullptr, 0u);
+    he = hipGetLastError();
+  }
   std::vector<uint8_t> emh((size_t)n * 512);
   if (he == hipSuccess && r == 0) he = hipMemcpyAsync(emh.data(), dem.p, emh.size(), hipMemcpyDeviceToHost, e->stream);
   hipError_t hs = hipStreamSynchronize(e->stream);

@@ -60,6 +60,9 @@ struct EmailMeta {
   uint32_t reuse;             // mode 1: the first DKIM-Signature is the verified one; scratch of the verify pass is reused
   uint32_t ed_key_bad;        // Ed25519 key is not a curve point (VerifyingKey::from_bytes fails): verdict = KEY_DECODE_FAIL
   uint32_t ed_ok;             // Ed25519 signature of this round's candidate verifies
+  uint32_t rsa_route;         // RSA_F_QUAD / RSA_F_OCT: the key's Montgomery constants are cached and a lane-group kernel takes the modexp (round 0)
+  uint32_t em_ok;             // the RSA role's result: EM = sig^e mod n has the EMSA-PKCS1-v1_5 shape for this signature's hash ...
+  uint32_t em_tail[8];        // ... and EM's trailing digest bytes (little-endian limbs), compared with the header hash by verdict_kernel
 };
 static_assert(sizeof(EmailMeta) % 8 == 0, "EmailMeta alignment");
 
@@ -618,7 +621,8 @@ __device__ __forceinline__ uint32_t der_uint(const Str& k, Win& w, uint32_t p, u
   return 1 + c + l;
 }
 // returns 0 or ZKE_D_KEY_*; fills the RSA job's modulus / exponent
-__device__ __forceinline__ uint32_t decode_rsa_key(const Str& k, RsaJob* J, uint32_t& bits_out, uint32_t& even) {
+__device__ __forceinline__ uint32_t decode_rsa_key(const Str& k, RsaJob* J, uint32_t& bits_out, uint32_t& even, uint32_t& np_out,
+                                                   uint32_t& nl_out, uint64_t& e_out) {
   Win w; w.wpos = WNONE; w.c = 0;
   const uint32_t len = k.len;
   if (len < 2 || at(k, w, 0) != 0x30) return ZKE_D_KEY_DER;
@@ -646,8 +650,30 @@ __device__ __forceinline__ uint32_t decode_rsa_key(const Str& k, RsaJob* J, uint
   }
   even = !(at(k, w, np + nl - 1) & 1) && bits != 0;
   if (lane_id() == 0) { J->e = e; J->k = nl; J->bits = bits; }
-  bits_out = bits;
+  bits_out = bits; np_out = np; nl_out = nl; e_out = e;
   return 0;
+}
+
+// Which RSA routine takes this key's signatures: RSA_F_QUAD / RSA_F_OCT when the lane-group kernel for its size is part of
+// the batch's launch (mask bit 0 / 1) and the key's Montgomery constants are in the cache — the modulus [np, np + nl) of
+// the DER key compared limb by limb with the entry, so a hit is exact; 0 = the one-signature-per-wave routine (which
+// fills the cache for the next batch).
+__device__ __forceinline__ uint32_t rsa_route(const Str& k, uint32_t np, uint32_t nl, uint32_t bits, const KeyCacheEntry* cache, uint32_t mask) {
+  // (the bits above RSA_F_* say why a key was not routed: zke_debug_out.rsa_route shows them to the tests)
+  if (bits < 512 || !(mask & (bits <= 2048 ? 1u : 2u))) return 0x100;
+  const uint32_t lane = (uint32_t)lane_id();
+  auto limb = [&](uint32_t L) -> uint32_t {       // little-endian 32-bit limb L of the big-endian modulus
+    uint32_t v = 0;
+#pragma unroll
+    for (uint32_t b = 0; b < 4; b++) { const uint32_t pos = 4 * L + b; if (pos < nl) v |= ldb(k, np + nl - 1 - pos) << (8 * b); }
+    return v;
+  };
+  const uint32_t l0 = limb(lane), l1 = limb(64 + lane);
+  const KeyCacheEntry* E = cache + key_cache_slot(__builtin_amdgcn_readfirstlane(l0), __builtin_amdgcn_readlane(l0, 1));
+  if (ld_agent(&E->state) != 2u) return 0x200;                      // not cached (yet)
+  if (ld_agent(&E->bits) != bits) return 0x400;                     // the slot belongs to another key
+  const bool same = ld_agent(&E->mod[lane]) == l0 && ld_agent(&E->mod[64 + lane]) == l1;
+  return __ballot(!same) == 0 ? (bits <= 2048 ? (uint32_t)RSA_F_QUAD : (uint32_t)RSA_F_OCT) : 0x400u;
 }
 
 // base64 STANDARD decode of tagbuf[off, off+n) into J->sig (right-aligned).  false = not canonical base64.
@@ -711,7 +737,14 @@ __device__ __forceinline__ bool same_bytes(const Str& v, uint32_t p, uint32_t a,
 // ------------------------------------------------------------------ the parse kernel
 // mode 0: verify_email_with_key scan (round r picks the r-th same-domain candidate)
 // mode 1: canonicalize_signed_email (first DKIM-Signature header, no domain filter; core/src/circuits.rs:34-35)
-struct ParseArgs { BatchDev b; uint32_t round; uint32_t mode; uint32_t debug_stop; uint32_t fuse_canon; };   // fuse_canon: canonicalise the body here (mode 0)
+struct ParseArgs {
+  BatchDev b; uint32_t round; uint32_t mode; uint32_t debug_stop;
+  uint32_t fuse_canon;              // canonicalise the body here (mode 0)
+  const KeyCacheEntry* cache;       // per-key Montgomery constants (nullptr: no cache, every signature takes the wave routine)
+  uint32_t route_mask;              // bit 0 / 1: the four- / eight-lane RSA kernel is part of this batch's hash / modexp launch
+  uint32_t* wave_count;             // job list of the one-signature-per-wave RSA routine: the e-mails not routed to a lane-group kernel
+  uint32_t* wave_list;              // (nullptr: no list, the routine looks at every job).  Appended here, consumed by the next launch.
+};
 
 // canon.hip.h
 __device__ __forceinline__ void canon_body_wave(const BatchDev& B, uint32_t i, uint32_t mode, uint32_t flags, uint32_t boff,
@@ -820,10 +853,13 @@ __global__ __launch_bounds__(64, 6) void parse_kernel(ParseArgs A) {
       if (lane == 0) M->key_ok = 2;
     } else {
       if (kt != ZKE_KEY_RSA) { finish(ZKE_KEY_DECODE_FAIL, ZKE_D_KEY_TYPE); return; }
-      uint32_t bits = 0, even = 0;
-      const uint32_t kr = decode_rsa_key(key, J, bits, even);
+      uint32_t bits = 0, even = 0, np = 0, nl = 0;
+      uint64_t ekey = 0;
+      const uint32_t kr = decode_rsa_key(key, J, bits, even, np, nl, ekey);
       if (kr) { finish(ZKE_KEY_DECODE_FAIL, kr); return; }
-      if (lane == 0) { R->rsa_bits = bits; M->key_ok = 1; M->even_modulus = even; }
+      uint32_t route = 0x800;           // no cache, no lane-group kernel in this launch, or an exponent / modulus they do not take
+      if (A.cache && A.route_mask && ekey == 65537 && !even) route = rsa_route(key, np, nl, bits, A.cache, A.route_mask);
+      if (lane == 0) { R->rsa_bits = bits; M->key_ok = 1; M->even_modulus = even; M->rsa_route = route; }
     }
     // the two output witnesses (core/src/circuits.rs:16-17)
     sha_job(2, dom.base, dom.len, R->from_domain_hash);
@@ -1061,7 +1097,10 @@ __global__ __launch_bounds__(64, 6) void parse_kernel(ParseArgs A) {
   if (lane == 0) {
     M->state = ST_CAND;
     // an Ed25519 candidate leaves the RSA job inactive; ed25519_email_kernel verifies it
-    J->flags = (cand_flags & ZKE_F_ED25519) ? 0u : (RSA_F_ACTIVE | ((cand_flags & ZKE_F_SHA1) ? (uint32_t)RSA_F_SHA1 : 0u));
+    const uint32_t jf = (cand_flags & ZKE_F_ED25519) ? 0u : (RSA_F_ACTIVE | ((cand_flags & ZKE_F_SHA1) ? (uint32_t)RSA_F_SHA1 : 0u) | (M->rsa_route & (RSA_F_QUAD | RSA_F_OCT)));
+    J->flags = jf;
+    M->em_ok = 0;
+    if ((jf & RSA_F_ACTIVE) && !(jf & (RSA_F_QUAD | RSA_F_OCT)) && A.wave_list) A.wave_list[atomicAdd(A.wave_count, 1u)] = i;
   }
   // ---- body canonicalisation of the candidate (cfdkim hash::compute_body_hash), same wave, no launch boundary
   if (A.fuse_canon) canon_body_wave(B, i, 0, cand_flags, body_off, raw.len - body_off, cand_len_tag, L.stage);   // parsing is over: the staged head is dead

@@ -23,8 +23,12 @@ int ensure_workspace(zke_engine* e, Slot& w, uint32_t n, uint64_t raw_total, boo
   const size_t scratch_bytes = 2 * (size_t)raw_total + (size_t)(n + 1) * SCR_PER_EMAIL + 256;
   if ((r = w.meta.ensure((size_t)n * sizeof(EmailMeta))) || (r = w.rsa_jobs.ensure((size_t)n * sizeof(RsaJob))) ||
       (r = w.sha_jobs.ensure((size_t)4 * n_pad * sizeof(ShaJob))) || (r = w.rsa_ok.ensure((size_t)n * 4)) ||
-      (r = w.scratch_off.ensure((size_t)(n + 1) * 16)) || (r = w.scratch.ensure(scratch_bytes)) || (r = w.pending.ensure(64)))
+      (r = w.scratch_off.ensure((size_t)(n + 1) * 16)) || (r = w.scratch.ensure(scratch_bytes)))
     return fail(e, r, "workspace allocation");
+  if (!w.pending.p) {       // counters: [0] e-mails pending another signature round, [2] length of the wave-routine job list (rsa_ok)
+    if ((r = w.pending.ensure(64))) return fail(e, r, "workspace allocation");
+    HIPCHK(e, hipMemset(w.pending.p, 0, 64));
+  }
   if (!e->wave_parse && (r = w.lanews.ensure((size_t)n * sizeof(LaneWs)))) return fail(e, r, "workspace allocation");
   if (want_em && (r = w.em_dbg.ensure((size_t)n * 512))) return fail(e, r, "workspace allocation");
   if (with_regex) {
@@ -40,6 +44,7 @@ int ensure_workspace(zke_engine* e, Slot& w, uint32_t n, uint64_t raw_total, boo
 // the registered tables: zke_dfa_register raises them.
 int set_kernel_attrs(zke_engine* e) {
   if (int r = set_sha_attrs_any(e)) return r;
+  if (int r = set_stage_attr_any(e)) return r;
   HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&front_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FRONT_LDS_BYTES));
   return 0;
 }
@@ -91,9 +96,14 @@ int run_device_pipeline(zke_engine* e, Slot& w, const zke_batch* in, uint64_t ra
   B.meta_verify = nullptr;
 
   const uint32_t rounds = max_rounds;
+  // an RSA-2048 key is 270 bytes of DER: a batch whose keys average more holds some larger modulus
+  const uint32_t route_mask = rsa_route_mask(e, n, e->batch_key_total > (uint64_t)n * 272);
   for (uint32_t round = round_begin; round < round_end; round++) {
+    // front end: parse, candidate signature, header-hash preimage, canonical body, RSA routing (parse.hip.h)
+    uint32_t* wave_count = e->wave_parse ? w.pending.as<uint32_t>() + 2 : nullptr;      // the lane-per-e-mail front end keeps no list
+    uint32_t* wave_list = e->wave_parse ? w.rsa_ok.as<uint32_t>() : nullptr;
     if (e->wave_parse) {
-      ParseArgs pa{B, round, 0, e->debug_parse_stop, e->fuse_canon};
+      ParseArgs pa{B, round, 0, e->debug_parse_stop, e->fuse_canon, e->key_cache.as<KeyCacheEntry>(), route_mask, wave_count, wave_list};
       hipLaunchKernelGGL(parse_kernel, dim3(n), dim3(64), 0, s, pa);
     } else {
       FrontArgs fa{B, w.lanews.as<LaneWs>(), round, 0, e->debug_parse_stop};
@@ -105,19 +115,15 @@ int run_device_pipeline(zke_engine* e, Slot& w, const zke_batch* in, uint64_t ra
       hipLaunchKernelGGL(canon_body_kernel, dim3(n), dim3(64), 0, s, ca);
     }
     if (round == 0) tm.mark();
-    if ((r = launch_sha_any(e, B.sha, 4 * n_pad, s))) return r;
-    if (round == 0) tm.mark();
-    if (!e->debug_skip_ed) {
-      EdArgs ea{B, round};        // Ed25519 keys / signatures (lane per e-mail); all-RSA waves exit after one load
-      hipLaunchKernelGGL(ed25519_email_kernel, dim3((n + 63) / 64), dim3(64), 0, s, ea);
-    }
-    FinArgs fa{B, round, rounds, w.pending.as<uint32_t>(), e->debug_skip_rsa};
-    if ((r = launch_rsa(e, B.rsa, n, reinterpret_cast<const uint8_t*>(out_dev) + offsetof(zke_result, header_hash),
-                        sizeof(zke_result), nullptr, want_em ? w.em_dbg.as<uint8_t>() : nullptr, s,
-                        e->batch_key_total > (uint64_t)n * 272 /* an RSA-2048 key is 270 bytes of DER: some key is larger */,
-                        e->key_cache.p ? reinterpret_cast<const uint8_t*>(out_dev) + offsetof(zke_result, public_key_hash) : nullptr, fa)))
+    // hash / modexp stage: the four SHA-256 jobs and the RSA operation of every e-mail, one launch (fused.hip.h)
+    if ((r = launch_hash_modexp(e, B.sha, 4 * n_pad, B.rsa, n, B.meta, want_em ? w.em_dbg.as<uint8_t>() : nullptr, route_mask,
+                                wave_count, wave_list, s)))
       return r;
-    if (round == 0) { tm.mark(); tm.mark(); }      // RSA + verdict are one launch now (finalize_us reads 0)
+    if (round == 0) tm.mark();
+    // Ed25519 stage + verdicts (verdict.hip.h): bh compare, EM digest against the header hash, status / detail, pending counter
+    EdVerdictArgs va{FinArgs{B, round, rounds, w.pending.as<uint32_t>(), e->debug_skip_rsa}, e->debug_skip_ed, wave_count};
+    hipLaunchKernelGGL(ed_verdict_kernel, dim3((n + 63) / 64), dim3(64), 0, s, va);
+    if (round == 0) { tm.mark(); tm.mark(); }      // sha_us = the hash / modexp launch, rsa_us = the Ed25519 + verdict launch (finalize_us reads 0)
   }
   HIPCHK(e, hipGetLastError());
 
@@ -128,7 +134,7 @@ int run_device_pipeline(zke_engine* e, Slot& w, const zke_batch* in, uint64_t ra
     B2.scratch = w.scratch2.as<uint8_t>();
     B2.meta_verify = B.meta;
     if (e->wave_parse) {
-      ParseArgs pa{B2, 0, 1, 0, 0};
+      ParseArgs pa{B2, 0, 1, 0, 0, nullptr, 0, nullptr, nullptr};
       hipLaunchKernelGGL(parse_kernel, dim3(n), dim3(64), 0, s, pa);
     } else {
       FrontArgs fa{B2, w.lanews.as<LaneWs>(), 0, 1, 0};
@@ -568,6 +574,7 @@ int zke_verify_batch(zke_engine* e, const zke_batch* in, zke_result* out, zke_de
       const uint8_t* body = m.body_src_is_raw ? in->raw_blob + in->raw_off[i] + m.body_off : regB;
       put(dbg->canon_body, dbg->canon_body_stride, i, body, hashed ? m.canon_full_len : 0);
       if (dbg->canon_body_full_len) dbg->canon_body_full_len[i] = hashed ? m.canon_full_len : 0;
+      if (dbg->rsa_route) dbg->rsa_route[i] = m.rsa_route;
       if (dbg->em) put(dbg->em, dbg->em_stride, i, em.data() + (size_t)i * 512 + 512 - std::min<uint32_t>(512, e_k(out[i].rsa_bits)),
                        std::min<uint32_t>(512, e_k(out[i].rsa_bits)));
       if (dbg->clean_body && in->with_regex && meta2[i].state == ST_CAND)

@@ -42,21 +42,29 @@ enum : uint32_t {
   RSA_F_OCT = 8,                // ... rsa_group_kernel<8> (eight lanes per signature: moduli of 2049..4096 bits)
 };
 
-// Per-key Montgomery constants, cached across e-mails and batches.  An entry is claimed once
-// (state 0 -> 1 by atomicCAS), written, published (state 2) and never modified again, so readers need
-// no lock: state == 2 + acquire, then compare the full SHA-256 of the key bytes.  A key whose slot is
-// owned by another key is simply not cached.
+// Per-key Montgomery constants, cached across e-mails and batches (one table per engine = per device, shared by all
+// submission slots).  Keyed by the MODULUS itself: the slot comes from a hash of its two low limbs and a hit needs all
+// limbs equal, so a lookup is exact and needs nothing but the decoded key — the front end does it (parse.hip.h) and
+// routes the signature to the lane-group kernel when the constants are there.  An entry is claimed once (state 0 -> 1 by
+// atomicCAS), written, published (state 2) and never modified again, so readers need no lock.  A key whose slot is owned
+// by another key is simply not cached.
 struct KeyCacheEntry {
   uint32_t state;               // 0 empty, 1 being filled, 2 valid
   uint32_t ninv;                // -n^-1 mod 2^32
   uint32_t bits;                // modulus bit length
   uint32_t pad;
-  uint32_t hash[8];             // SHA-256 of the DER key (zke_result.public_key_hash)
+  uint32_t mod[128];            // the modulus, little-endian 32-bit limbs (zero above `bits`)
   uint32_t rr[128];             // R^2 mod n, limb q*64+lane
   uint32_t rr28[152];           // rsa_quad.hip.h: 2^4256 mod n as 76 limbs of 28 bits (512..2048 bits), 2^8512 mod n as 152 (..4096)
 };
-static_assert(sizeof(KeyCacheEntry) == 1168, "KeyCacheEntry layout");
+static_assert(sizeof(KeyCacheEntry) == 1648, "KeyCacheEntry layout");
 constexpr uint32_t KEY_CACHE_SLOTS = 4096;
+__host__ __device__ inline uint32_t key_cache_slot(uint32_t n0, uint32_t n1) { return (n0 * 0x9E3779B1u + n1 * 0x85EBCA77u) >> 20; }   // 12 bits
+static_assert(KEY_CACHE_SLOTS == (1u << 12), "key_cache_slot yields 12 bits");
+
+// agent-scope (sc1) accesses: served at the coherence point, not from this XCD's L2
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // ---- cross-lane helpers -------------------------------------------------------------
 // value of lane+1 (lane 63 gets 0): v_mov_b32_dpp wave_shl:1 bound_ctrl:0

@@ -1,22 +1,68 @@
-// rsa_kernel.hip.h — the RSA verification kernel (bigint core in rsa.hip.h) with the per-e-mail verdict fused in.
+// rsa_kernel.hip.h — the RSA public-key operation of one signature per wavefront (bigint core in rsa.hip.h), as a
+// device routine (rsa_wave) and as a stand-alone kernel, and the verdict kernel that follows the hash / modexp stage.
+//
+// The modular exponentiation needs the key and b= only — not the hashes — so it runs BESIDE the SHA-256 launch of its
+// batch (fused.hip.h), not behind it: it leaves "EM has the EMSA-PKCS1-v1_5 shape" and EM's trailing digest bytes in
+// EmailMeta, and verdict_kernel compares those bytes with the header hash once both are there
+// (rsa 0.9.6 pkcs1v15 verify, reached through cfdkim's verify_signature; call site core/src/email.rs:31-33).
 #pragma once
 #include "canon.hip.h"
 
 namespace zke {
 
-// One wave per job.  blockDim = 64, grid = n.  When `fin.b.results` is set the wave also
-// writes the e-mail's verdict (the former finalize kernel: one launch and ~20 us of serial loads less per batch).
-// ok_out[i]: 1 = signature verifies (EM == EMSA(hash)), 0 = not.  em_out (optional): EM big-endian, 512 B slots,
-// right-aligned like RsaJob.sig.  hash_base + i*hash_stride -> 32-byte SHA-256 of the header preimage.
+// Is E the published entry of modulus nn?  Every access to an entry is an agent-scope atomic (sc1: served at the
+// coherence point, not from this XCD's L2), so no fence is needed on either side: an agent-scope acquire / release on
+// this chip is an L2 invalidate / write-back, paid by every wave of the launch and by whatever else runs on the XCD.
+// The entry is immutable once state == 2, and the state load is waited for before the other loads issue.
+template <int NL>
+__device__ __forceinline__ bool key_cache_hit(const KeyCacheEntry* E, const Big<NL>& nn, uint32_t bits) {
+  if (ld_agent(&E->state) != 2u || ld_agent(&E->bits) != bits) return false;
+  const int lane = threadIdx.x & 63;
+  bool same = true;
+#pragma unroll
+  for (int q = 0; q < NL; q++) same = same && ld_agent(&E->mod[q * 64 + lane]) == nn.v[q];
+  return ballot64(!same) == 0;
+}
+
+// EMSA-PKCS1-v1_5 structure in front of the digest: do the limbs of em above the digest (limb >= hl / 4) spell
+// 00 01 FF..FF 00 | DigestInfo?  (emsa_byte never touches the hash words for q >= hl.)
+template <int NL>
+__device__ __forceinline__ bool emsa_structure_ok(const Big<NL>& em, uint32_t k, bool sha1, int lane) {
+  const uint32_t hl4 = sha1 ? 5u : 8u;
+  bool match = k >= (sha1 ? 46u : 62u);                    // k >= tLen + 11
+#pragma unroll
+  for (int q = 0; q < NL; q++) {
+    const uint32_t limb = q * 64 + lane;
+    uint32_t expect = 0;
+    if (limb >= hl4) {
+#pragma unroll
+      for (int b = 0; b < 4; b++) expect |= emsa_byte(4 * limb + b, k, nullptr, sha1) << (8 * b);
+    }
+    match = match && (ballot64(limb >= hl4 && em.v[q] != expect) == 0);
+  }
+  return match;
+}
+// EM's trailing digest, held as little-endian limbs tail[l] (l < hl / 4), against the digest words hw as stored in memory
+__device__ __forceinline__ bool emsa_tail_ok(uint32_t tail_of_lane, const uint32_t* hw, bool sha1, int lane) {
+  const uint32_t hl4 = sha1 ? 5u : 8u;
+  bool bad = false;
+  if ((uint32_t)lane < hl4) bad = tail_of_lane != __builtin_bswap32(hw[hl4 - 1 - lane]);
+  return ballot64(bad) == 0;
+}
+
+// One wave per job.  Jobs routed to the lane-group kernels (RSA_F_QUAD / RSA_F_OCT, set by the front end) are left alone.
+//   meta != nullptr: the batch pipeline — em_ok / em_tail go to EmailMeta[job] for verdict_kernel.
+//   hash_base != nullptr: the building-block entry point — the digest is at hand, ok_out[job] = full verification.
+// em_out (optional): EM big-endian, 512 B slots, right-aligned like RsaJob.sig.
 template <int NL>
 __device__ __forceinline__ void rsa_wave(const RsaJob* __restrict__ jobs, uint32_t job,
                                          const uint8_t* __restrict__ hash_base, size_t hash_stride,
                                          uint32_t* __restrict__ ok_out, uint8_t* __restrict__ em_out,
-                                         KeyCacheEntry* cache, const uint8_t* __restrict__ key_hash_base,
-                                         const FinArgs& fin, uint32_t quad) {
+                                         KeyCacheEntry* cache, EmailMeta* meta, uint32_t debug_skip) {
   const int lane = threadIdx.x & 63;
   const RsaJob* J = jobs + job;
   const uint32_t flags = J->flags, k = J->k, bits = J->bits;
+  if (flags & (RSA_F_QUAD | RSA_F_OCT)) return;
 
   Big<NL> nn, s;
 #pragma unroll
@@ -27,46 +73,30 @@ __device__ __forceinline__ void rsa_wave(const RsaJob* __restrict__ jobs, uint32
     s.v[q] = __builtin_bswap32(*(const uint32_t*)(J->sig + boff));
   }
   uint32_t ok = 0;
-  const bool odd = (__builtin_amdgcn_readfirstlane(nn.v[0]) & 1) != 0;
+  bool shape_ok = false;
+  const uint32_t n0 = __builtin_amdgcn_readfirstlane(nn.v[0]), n1 = __builtin_amdgcn_readlane(nn.v[0], 1);
+  const bool odd = (n0 & 1) != 0;
   const bool lenok = J->sig_len == k;             // rsa 0.9.6 pkcs1v15::verify: sig_len != pub_key.size() -> Err
+  const bool sha1 = (flags & RSA_F_SHA1) != 0;
   Big<NL> em;
 #pragma unroll
   for (int q = 0; q < NL; q++) em.v[q] = 0;
-  if ((flags & RSA_F_ACTIVE) && odd && lenok && bits >= 2 && !big_ge<NL>(s, nn) && !fin.debug_skip_rsa) {
+  if ((flags & RSA_F_ACTIVE) && odd && lenok && bits >= 2 && !big_ge<NL>(s, nn) && !debug_skip) {
     Big<NL> rr;
     uint32_t ninv = 0;
     bool hit = false;
     KeyCacheEntry* E = nullptr;
-    const uint32_t* kh = nullptr;
-    // Pre-pass for rsa_group_kernel: e = 65537, 512..2048 bits and the key's constants in the cache (found there, or put
-    // there by this wave) -> the job is marked and left to that kernel, verdict included.
-    const bool quad_ok = (quad & (NL == 1 ? 1u : 2u)) && cache && fin.b.results && bits >= 512 && J->e == 65537;
-    constexpr uint32_t GROUP_FLAG = NL == 1 ? RSA_F_QUAD : RSA_F_OCT;
     if (cache) {
-      kh = (const uint32_t*)(key_hash_base + (size_t)job * hash_stride);
-      E = cache + (kh[0] % KEY_CACHE_SLOTS);
-      // Every access to an entry is an agent-scope atomic (sc1: served at the coherence point, not from this XCD's
-      // L2), so no fence is needed on either side: an agent-scope acquire / release on this chip is an L2
-      // invalidate / write-back, paid by every wave of the launch and by whatever else runs on the XCD.
-      // The entry is immutable once state == 2, and the state load is waited for before the other loads issue.
-      auto ld = [](const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-      if (ld(&E->state) == 2u) {
-        const bool same = (lane < 8) ? (ld(&E->hash[lane]) == kh[lane]) : true;
-        if (ballot64(!same) == 0 && ld(&E->bits) == bits) {
+      E = cache + key_cache_slot(n0, n1);
+      if (key_cache_hit<NL>(E, nn, bits)) {
 #pragma unroll
-          for (int q = 0; q < NL; q++) rr.v[q] = ld(&E->rr[q * 64 + lane]);
-          ninv = ld(&E->ninv);
-          hit = true;
-        }
+        for (int q = 0; q < NL; q++) rr.v[q] = ld_agent(&E->rr[q * 64 + lane]);
+        ninv = ld_agent(&E->ninv);
+        hit = true;
       }
-    }
-    if (hit && quad_ok) {
-      if (lane == 0) const_cast<RsaJob*>(J)->flags = flags | GROUP_FLAG;
-      return;
     }
     if (!hit) {
       // ninv = -n^-1 mod 2^32 (Newton; n odd)
-      uint32_t n0 = __builtin_amdgcn_readfirstlane(nn.v[0]);
       uint32_t x = n0;
 #pragma unroll
       for (int i = 0; i < 5; i++) x *= 2 - n0 * x;
@@ -94,11 +124,11 @@ __device__ __forceinline__ void rsa_wave(const RsaJob* __restrict__ jobs, uint32
         if (lane == 0) won = atomicCAS(&E->state, 0u, 1u) == 0u ? 1u : 0u;
         won = __builtin_amdgcn_readfirstlane(won);
         if (won) {
-          auto st = [](uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-          if (lane < 8) st(&E->hash[lane], kh[lane]);
-          if (lane == 0) { st(&E->ninv, ninv); st(&E->bits, bits); }
+          if (lane == 0) { st_agent(&E->ninv, ninv); st_agent(&E->bits, bits); }
 #pragma unroll
-          for (int q = 0; q < NL; q++) st(&E->rr[q * 64 + lane], rr.v[q]);
+          for (int q = 0; q < 2; q++) st_agent(&E->mod[q * 64 + lane], q < NL ? nn.v[q < NL ? q : 0] : 0u);
+#pragma unroll
+          for (int q = 0; q < NL; q++) st_agent(&E->rr[q * 64 + lane], rr.v[q]);
           if (bits >= 512) {
             // R'^2 mod n for the 28-bit radix of rsa_quad.hip.h (R' = 2^(532 G): 2^2128 for four lanes, 2^4256 for eight):
             // two more products with R = 2^(2048 NL): mont(R^2, 2^c) = 2^c R, mont(R^2, 2^c R) = 2^c R^2 with
@@ -119,15 +149,11 @@ __device__ __forceinline__ void rsa_wave(const RsaJob* __restrict__ jobs, uint32
                 if (((w + 1) >> 6) == (uint32_t)q) hi = l1;
               }
               const uint32_t v = (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (bit & 31)) & 0x0FFFFFFFu;
-              if (t < 76u * NL) st(&E->rr28[t], v);
+              if (t < 76u * NL) st_agent(&E->rr28[t], v);
             }
           }
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the entry has reached the coherence point ...
-          if (lane == 0) st(&E->state, 2u);                        // ... before it is published
-          if (quad_ok) {
-            if (lane == 0) const_cast<RsaJob*>(J)->flags = flags | GROUP_FLAG;
-            return;
-          }
+          if (lane == 0) st_agent(&E->state, 2u);                  // ... before it is published
         }
       }
     }
@@ -145,22 +171,16 @@ __device__ __forceinline__ void rsa_wave(const RsaJob* __restrict__ jobs, uint32
 #pragma unroll
     for (int q = 0; q < NL; q++) lit.v[q] = (q == 0 && lane == 0) ? 1u : 0u;
     mont_mul<NL>(em, acc, lit, nn, ninv, lane);              // out of the Montgomery domain
-    // EMSA-PKCS1-v1_5 compare (rsa 0.9.6 pkcs1v15_sign_unpad); needs k >= 19 + 32 + 11
-    const uint32_t* hw = (const uint32_t*)(hash_base + (size_t)job * hash_stride);
-    const bool sha1 = (flags & RSA_F_SHA1) != 0;
-    bool match = k >= (sha1 ? 46u : 62u);                    // k >= tLen + 11
-#pragma unroll
-    for (int q = 0; q < NL; q++) {
-      const uint32_t limb = q * 64 + lane;
-      uint32_t expect = 0;
-#pragma unroll
-      for (int b = 0; b < 4; b++) expect |= emsa_byte(4 * limb + b, k, hw, sha1) << (8 * b);
-      match = match && (ballot64(em.v[q] != expect) == 0);
-    }
-    ok = match ? 1u : 0u;
+    shape_ok = emsa_structure_ok<NL>(em, k, sha1, lane);     // rsa 0.9.6 pkcs1v15_sign_unpad, all but the digest
+    if (hash_base)
+      ok = (shape_ok && emsa_tail_ok(em.v[0], (const uint32_t*)(hash_base + (size_t)job * hash_stride), sha1, lane)) ? 1u : 0u;
   }
   if (lane == 0 && ok_out) ok_out[job] = ok;
-  if (fin.b.results) verdict_wave(fin, job, ok != 0, lane);
+  if (meta) {
+    EmailMeta* M = meta + job;
+    if (lane < 8) M->em_tail[lane] = em.v[0];
+    if (lane == 0) M->em_ok = shape_ok ? 1u : 0u;
+  }
   if (em_out && (flags & RSA_F_ACTIVE)) {     // inactive jobs (later signature rounds) leave the slot alone
 #pragma unroll
     for (int q = 0; q < NL; q++) {
@@ -171,20 +191,23 @@ __device__ __forceinline__ void rsa_wave(const RsaJob* __restrict__ jobs, uint32
   }
 }
 
+// a wave picks the one-limb-per-lane (<= 2048 bits) or two-limbs-per-lane path from its job's modulus size
+__device__ __forceinline__ void rsa_wave_any(const RsaJob* __restrict__ jobs, uint32_t job, const uint8_t* __restrict__ hash_base,
+                                             size_t hash_stride, uint32_t* __restrict__ ok_out, uint8_t* __restrict__ em_out,
+                                             KeyCacheEntry* cache, EmailMeta* meta, uint32_t debug_skip) {
+  const uint32_t bits = __builtin_amdgcn_readfirstlane(jobs[job].bits);
+  if (bits <= 2048) rsa_wave<1>(jobs, job, hash_base, hash_stride, ok_out, em_out, cache, meta, debug_skip);
+  else rsa_wave<2>(jobs, job, hash_base, hash_stride, ok_out, em_out, cache, meta, debug_skip);
+}
 
-// One kernel for both containers: a wave picks the one-limb-per-lane (<= 2048 bits) or two-limbs-per-lane path
-// from its job's modulus size (wave-uniform branch).
+// Stand-alone launch (launches too large for the fused kernel, the building-block entry point): grid = n, blockDim = 64.
 __global__ __launch_bounds__(64, 6) void rsa_verify_kernel(const RsaJob* __restrict__ jobs, uint32_t n,
                                                          const uint8_t* __restrict__ hash_base, size_t hash_stride,
                                                          uint32_t* __restrict__ ok_out, uint8_t* __restrict__ em_out,
-                                                         KeyCacheEntry* cache, const uint8_t* __restrict__ key_hash_base,
-                                                         FinArgs fin, uint32_t quad) {
+                                                         KeyCacheEntry* cache, EmailMeta* meta, uint32_t debug_skip) {
   const uint32_t job = blockIdx.x;      // one wave per workgroup: a single free wave slot is enough to place it
   if (job >= n) return;
-  if (fin.b.results && fin.b.meta[job].state == ST_PENDING) return;     // waits for a later signature round
-  const uint32_t bits = __builtin_amdgcn_readfirstlane(jobs[job].bits);
-  if (bits <= 2048) rsa_wave<1>(jobs, job, hash_base, hash_stride, ok_out, em_out, cache, key_hash_base, fin, quad);
-  else rsa_wave<2>(jobs, job, hash_base, hash_stride, ok_out, em_out, cache, key_hash_base, fin, quad);
+  rsa_wave_any(jobs, job, hash_base, hash_stride, ok_out, em_out, cache, meta, debug_skip);
 }
 
 }  // namespace zke

@@ -18,11 +18,11 @@
 // 55 instructions per step for 16 signatures instead of 9 per step for one.  Moduli of 2049..4096 bits run the same
 // code with eight lanes per signature (152 limbs, R = 2^4256, eight blocks of 19 steps).
 //
-// R^2 mod n for this radix (2^4256 mod n; 2^8512 mod n for eight lanes) comes from the key cache: rsa_verify_kernel
-// runs first as a pre-pass, fills the entry of a key it sees for the first time (two more 32-bit-radix Montgomery
-// products turn 2^4096 mod n into 2^4256 mod n) and marks the jobs these kernels take with RSA_F_QUAD / RSA_F_OCT;
-// everything else — other exponents, keys whose cache slot belongs to another key, signatures rsa 0.9.6 rejects before the
-// arithmetic — stays with the one-signature-per-wave path.  The algorithm and its register bounds are modelled with
+// R^2 mod n for this radix (2^4256 mod n; 2^8512 mod n for eight lanes) comes from the key cache.  The front end looks a
+// decoded key up there (by modulus: exact) and routes the e-mail's signatures here (RSA_F_QUAD / RSA_F_OCT) when the
+// entry exists and e = 65537; a key seen for the first time — and other exponents, keys whose cache slot belongs to
+// another key — goes to the one-signature-per-wave routine, which fills the entry (two more 32-bit-radix Montgomery
+// products turn 2^4096 mod n into 2^4256 mod n).  Signatures rsa 0.9.6 rejects before the arithmetic are rejected here too.  The algorithm and its register bounds are modelled with
 // Python integers in tests/test_rsa_group_model.py.
 #pragma once
 #include "rsa_kernel.hip.h"
@@ -115,28 +115,30 @@ __device__ __forceinline__ void qnorm(QBig& out, const uint64_t (&W)[2 * QL], in
   out.v[0] += last;                                             // value-preserving; zero after G - 1 passes
 }
 
+// One wave: NG = 64 / G signatures.  job0 = the wave's first job.  Llimb: NG x (G * QL + 4) dwords of LDS private to the wave.
+//   meta != nullptr: em_ok / em_tail of each signature go to EmailMeta for verdict_kernel (the batch pipeline);
+//   hash_base != nullptr: the digest is at hand, ok_out[job] = full verification.
 template <int G>
-__global__ __launch_bounds__(64) void rsa_group_kernel(const RsaJob* __restrict__ jobs, uint32_t n,
-                                                       const uint8_t* __restrict__ hash_base, size_t hash_stride,
-                                                       uint32_t* __restrict__ ok_out, uint8_t* __restrict__ em_out,
-                                                       const KeyCacheEntry* cache, const uint8_t* __restrict__ key_hash_base,
-                                                       FinArgs fin) {
+__device__ __forceinline__ void rsa_group_wave(const RsaJob* __restrict__ jobs, uint32_t n, uint32_t job0, uint32_t* Llimb_raw,
+                                               const uint8_t* __restrict__ hash_base, size_t hash_stride,
+                                               uint32_t* __restrict__ ok_out, uint8_t* __restrict__ em_out,
+                                               const KeyCacheEntry* cache, EmailMeta* meta) {
   constexpr int NG = 64 / G, LIMBS = G * QL;
   constexpr uint32_t MY_FLAG = G == 4 ? RSA_F_QUAD : RSA_F_OCT;
-  __shared__ uint32_t Llimb[NG][LIMBS + 4];
+  uint32_t (*Llimb)[LIMBS + 4] = reinterpret_cast<uint32_t (*)[LIMBS + 4]>(Llimb_raw);
 #ifndef ZKE_QUAD_PRIO
 #define ZKE_QUAD_PRIO 3
 #endif
-  // NG signatures share one long dependency chain (~95 k instructions for G = 4): served round-robin with the short waves
-  // of other batches it would stretch several times over and hold its whole batch back; the others have parallel slack.
-  __builtin_amdgcn_s_setprio(ZKE_QUAD_PRIO);
   const int lane = threadIdx.x & 63, p = lane & (G - 1), grp = lane / G;
-  const uint32_t job = blockIdx.x * NG + grp;
+  const uint32_t job = job0 + grp;
   const RsaJob* J = jobs + (job < n ? job : 0);
   uint32_t flags = 0;
   if (job < n) flags = J->flags;
   const bool act = (flags & MY_FLAG) != 0;
   if (__ballot(act) == 0) return;
+  // NG signatures share one long dependency chain (~95 k instructions for G = 4): served round-robin with the short waves
+  // of other batches it would stretch several times over and hold its whole batch back; the others have parallel slack.
+  __builtin_amdgcn_s_setprio(ZKE_QUAD_PRIO);
 
   QBig nn, s, rr;
 #pragma unroll
@@ -151,17 +153,32 @@ __global__ __launch_bounds__(64) void rsa_group_kernel(const RsaJob* __restrict_
       const uint64_t v = __builtin_bswap64(*(const u64_unaligned*)(field + 504 - oo)) >> (8 * (o - oo));
       return (uint32_t)(v >> (bit & 7)) & QMASK;
     };
-    const uint32_t* kh = (const uint32_t*)(key_hash_base + (size_t)job * hash_stride);
-    const KeyCacheEntry* E = cache + (kh[0] % KEY_CACHE_SLOTS);
-    auto ld = [](const uint32_t* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    // the front end found this modulus in the cache (all limbs compared) before it set MY_FLAG; entries are immutable
+    const uint32_t n0 = __builtin_bswap32(*(const uint32_t*)(J->mod + 508)), n1 = __builtin_bswap32(*(const uint32_t*)(J->mod + 504));
+    const KeyCacheEntry* E = cache + key_cache_slot(n0, n1);
 #pragma unroll
     for (int j = 0; j < QL; j++) {
       nn.v[j] = limb_of(J->mod, QL * p + j);
       s.v[j] = limb_of(J->sig, QL * p + j);
-      rr.v[j] = ld(&E->rr28[QL * p + j]);
+      rr.v[j] = ld_agent(&E->rr28[QL * p + j]);
     }
-    ninv = ld(&E->ninv) & QMASK;
+    ninv = ld_agent(&E->ninv) & QMASK;
     kbytes = J->k;
+  }
+  {
+    // rsa 0.9.6 rejects a signature whose length is not the modulus length, or with s >= n, before any arithmetic:
+    // such a job runs with s = 0, whose EM = 0 has no EMSA shape (em_ok = 0, an all-zero EM block, as the wave path leaves).
+    // s >= n: per lane the sign of the highest differing limb; the highest lane of the group that differs decides.
+    int c = 0;
+#pragma unroll
+    for (int j = QL - 1; j >= 0; j--) c = c != 0 ? c : (int)(s.v[j] > nn.v[j]) - (int)(s.v[j] < nn.v[j]);
+    const uint64_t gmask0 = (G == 4 ? 0xFull : 0xFFull);
+    const uint64_t gtg = (__ballot(c > 0) >> (G * grp)) & gmask0, ltg = (__ballot(c < 0) >> (G * grp)) & gmask0;
+    const bool reject = act && (J->sig_len != kbytes || gtg >= ltg);
+    if (reject) {
+#pragma unroll
+      for (int j = 0; j < QL; j++) s.v[j] = 0;
+    }
   }
 
   // s^65537: into the Montgomery domain, 16 squarings, one multiplication, out again
@@ -184,22 +201,30 @@ __global__ __launch_bounds__(64) void rsa_group_kernel(const RsaJob* __restrict_
     qnorm<G, G - 1>(acc, W, p);               // EM, exact: < n
   }
 
-  // EMSA-PKCS1-v1_5 compare (rsa 0.9.6 pkcs1v15_sign_unpad), byte by byte through LDS
+  // EMSA-PKCS1-v1_5 (rsa 0.9.6 pkcs1v15_sign_unpad), byte by byte through LDS: the structure in front of the digest is
+  // checked here; the digest bytes are compared now (hash_base) or handed to verdict_kernel (meta)
 #pragma unroll
   for (int j = 0; j < QL; j++) Llimb[grp][QL * p + j] = acc.v[j];
   if (p < 4) Llimb[grp][LIMBS + p] = 0;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   const bool sha1 = (flags & RSA_F_SHA1) != 0;
-  bool bad = false;
+  const uint32_t hl = sha1 ? 20u : 32u;
+  bool bad = false, tail_bad = false;
   if (act) {
-    const uint32_t* hw = (const uint32_t*)(hash_base + (size_t)job * hash_stride);
+    const uint32_t* hw = hash_base ? (const uint32_t*)(hash_base + (size_t)job * hash_stride) : nullptr;
+    uint8_t* tail = meta ? reinterpret_cast<uint8_t*>(meta[job].em_tail) : nullptr;
     for (uint32_t u = 0; u < 64; u++) {
       const uint32_t i = G * u + (uint32_t)p;                    // little-endian byte index: 64 G bytes per group
       const uint32_t t = (8 * i) / 28, sh = 8 * i - 28 * t;
       const uint64_t two = (uint64_t)Llimb[grp][t] | ((uint64_t)Llimb[grp][t + 1] << 28);
       const uint32_t got = (uint32_t)(two >> sh) & 0xff;
-      bad = bad || got != emsa_byte(i, kbytes, hw, sha1);
+      if (i < hl) {
+        if (tail) tail[i] = (uint8_t)got;                        // little-endian limb image: byte i of EM counted from its end
+        if (hw) tail_bad = tail_bad || got != emsa_byte(i, kbytes, hw, sha1);
+      } else {
+        bad = bad || got != emsa_byte(i, kbytes, nullptr, sha1);
+      }
       if (em_out) em_out[(size_t)job * 512 + 511 - i] = (uint8_t)got;
     }
     if (em_out && G == 4) {
@@ -207,15 +232,23 @@ __global__ __launch_bounds__(64) void rsa_group_kernel(const RsaJob* __restrict_
       for (int z = 0; z < 16; z++) *(uint32_t*)(em_out + (size_t)job * 512 + 64 * p + 4 * z) = 0;     // upper half of the slot
     }
   }
-  const uint64_t badm = __ballot(bad);
+  const uint64_t badm = __ballot(bad), tbadm = __ballot(tail_bad);
   const uint64_t gmask = (G == 4 ? 0xFull : 0xFFull);
-  const bool ok = act && ((badm >> (G * grp)) & gmask) == 0 && kbytes >= (sha1 ? 46u : 62u);      // k >= tLen + 11
-  if (act && p == 0 && ok_out) ok_out[job] = ok ? 1u : 0u;
-  if (fin.b.results) {
-    const uint64_t actm = __ballot(act && p == 0), okm = __ballot(ok && p == 0);
-    for (int g2 = 0; g2 < NG; g2++)
-      if ((actm >> (G * g2)) & 1) verdict_wave(fin, blockIdx.x * NG + g2, ((okm >> (G * g2)) & 1) != 0, lane);
+  const bool shape_ok = act && ((badm >> (G * grp)) & gmask) == 0 && kbytes >= (sha1 ? 46u : 62u);      // k >= tLen + 11
+  if (act && p == 0) {
+    if (ok_out) ok_out[job] = (hash_base && shape_ok && ((tbadm >> (G * grp)) & gmask) == 0) ? 1u : 0u;
+    if (meta) meta[job].em_ok = shape_ok ? 1u : 0u;
   }
+}
+
+template <int G>
+__global__ __launch_bounds__(64) void rsa_group_kernel(const RsaJob* __restrict__ jobs, uint32_t n,
+                                                       const uint8_t* __restrict__ hash_base, size_t hash_stride,
+                                                       uint32_t* __restrict__ ok_out, uint8_t* __restrict__ em_out,
+                                                       const KeyCacheEntry* cache, EmailMeta* meta) {
+  constexpr int NG = 64 / G, LIMBS = G * QL;
+  __shared__ uint32_t Llimb[NG * (LIMBS + 4)];
+  rsa_group_wave<G>(jobs, n, blockIdx.x * NG, Llimb, hash_base, hash_stride, ok_out, em_out, cache, meta);
 }
 
 }  // namespace zke

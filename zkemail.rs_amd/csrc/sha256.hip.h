@@ -266,13 +266,15 @@ constexpr int SHA_KW_ROW = 68;        // dwords per lane and buffer
 template <int T>
 constexpr size_t sha256_pair_lds_bytes() { return 64 * (T + 16) + 64 * 16 + 64 * SHA_KW_ROW * 4; }
 
+// The two waves of workgroup-local threads 0..127 hash messages [64 group, 64 group + 64); lds_raw: sha256_pair_lds_bytes<T>()
+// of 16-byte aligned LDS.  A device routine so that other work can share the launch (fused.hip.h); both waves of the
+// workgroup must call it (it uses __syncthreads()).
 template <int T>
-__global__ __launch_bounds__(128) void sha256_pair_kernel(const ShaJob* __restrict__ jobs, uint32_t n) {
+__device__ __forceinline__ void sha256_pair_group(const ShaJob* __restrict__ jobs, uint32_t n, uint32_t group, uint8_t* lds_raw) {
   static_assert(T % 64 == 0 && T >= 64 && T <= 1024, "tile must be whole SHA blocks");
   constexpr int ROW = T + 16;
   constexpr int LPR = T / 16;
   constexpr int RPI = 64 / LPR;
-  extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
 #ifndef ZKE_SHA_PRIO
 #define ZKE_SHA_PRIO 3
 #endif
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(128) void sha256_pair_kernel(const ShaJob* __restri
   uint8_t* desc = slab + 64 * ROW;
   uint32_t* kw = (uint32_t*)(desc + 64 * 16);      // [64 lanes][SHA_KW_ROW]: a lane's 64 words are contiguous (b128 accesses)
 
-  const uint32_t m = blockIdx.x * 64 + lane;       // both waves look at the same 64 jobs
+  const uint32_t m = group * 64 + lane;            // both waves look at the same 64 jobs
   uint64_t my_src = 0, my_dst = 0;
   uint32_t my_len = 0, my_nblk = 0, my_algo = 0;
   if (m < n) {
@@ -468,6 +470,12 @@ __global__ __launch_bounds__(128) void sha256_pair_kernel(const ShaJob* __restri
 #pragma unroll
     for (int i = 0; i < 8; i++) out[i] = (my_algo && i >= 5) ? 0u : __builtin_bswap32(st[i]);
   }
+}
+
+template <int T>
+__global__ __launch_bounds__(128) void sha256_pair_kernel(const ShaJob* __restrict__ jobs, uint32_t n) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+  sha256_pair_group<T>(jobs, n, blockIdx.x, lds_raw);
 }
 
 }  // namespace zke
