@@ -181,12 +181,12 @@ typedef struct zke_debug_out {
 
 typedef struct zke_options {
   int32_t  device;        /* HIP device ordinal; -1 = current */
-  /* reserved[0]: max signature rounds in host mode (default 4; rounds beyond the first run only while some
-   *              e-mail's earlier same-domain signature failed and a later one exists).
-   * reserved[1]: signature rounds in device mode (default 1; fixed, nothing is read back).  An e-mail that
-   *              needs more reports ZKE_UNSUPPORTED / ZKE_D_U_TOO_MANY_SIGS.
-   * reserved[2]: unused (0).
-   * reserved[3]: non-zero disables the per-key Montgomery-constant cache of the RSA kernel.  Others: 0. */
+  /* reserved[0]: how many same-domain DKIM-Signature headers are tried per e-mail, in file order, until one passes —
+   *              cfdkim tries them all; default 16, at most ZKE_MAX_HEADERS.  The first is tried in the batch's three
+   *              launches, later ones inside the last of them by the e-mail's own wave (both entry points alike, nothing is
+   *              read back).  An e-mail with more failing candidates reports ZKE_UNSUPPORTED / ZKE_D_U_TOO_MANY_SIGS.
+   * reserved[1], reserved[2]: unused (0).
+   * reserved[3]: non-zero disables the per-key Montgomery-constant cache of the RSA kernels.  Others: 0. */
   uint32_t reserved[7];
 } zke_options;
 

@@ -285,10 +285,12 @@ def test_rsa_routing_through_the_key_cache(engine, oracle):
     assert_records_equal(got1, exp, None, "routing, first batch")
     assert_records_equal(got2, exp, None, "routing, second batch")
     assert ((d1.rsa_route & 12) == 0).all(), d1.rsa_route          # fresh keys: nothing cached (0x200), or no lane-group kernel (0x800)
+    assert not forced or sum(int(x) in (4, 8) for x in d3.rsa_route) >= 20          # at most one of the four fresh keys may collide
     for i in range(40):
         bits = fresh[i % 4].bits
         want = (4 if bits <= 2048 else 8) if forced else int(d3.rsa_route[i])
-        assert int(d3.rsa_route[i]) == want, (i, bits, [hex(int(x)) for x in d1.rsa_route[:4]], [hex(int(x)) for x in d3.rsa_route[:8]])
+        # (0x400: the key's cache slot already belongs to another key of this session — it stays with the wave routine)
+        assert int(d3.rsa_route[i]) in (want, 0x400), (i, bits, [hex(int(x)) for x in d1.rsa_route[:4]], [hex(int(x)) for x in d3.rsa_route[:8]])
         if inter[i] is None:
             assert int(got2[i]["status"]) == A.ZKE_DKIM_NOT_PASS and int(got2[i]["detail"]) == A.D_SIG_MISMATCH, i
             assert not d1.em[i].any() and not d3.em[i].any(), i
@@ -310,16 +312,32 @@ def test_limits_and_large_header_blocks_parity(engine, oracle):
 
 
 def test_signature_rounds(engine, oracle):
-    """Host mode adds signature rounds while e-mails are pending (default up to 4): 3 failing same-domain
-    signatures then a good one verifies; 5 failing ones exceed the rounds and are reported, never guessed."""
-    cs = [cases.multi_signature_case(k) for k in (1, 2, 3)]
-    got, exp, _, _ = run_both(engine, oracle, [c.email for c in cs])
+    """cfdkim tries an e-mail's same-domain signatures one after the other (behind core/src/email.rs:31-33).  The first
+    is tried in the batch's launches, later ones by the e-mail's own wave inside the verdict launch — the same for the
+    host and the device entry point: 1, 2, 3, 5 and 12 failing signatures in front of the good one verify with the
+    oracle's sig_index; the default cap is 16 candidates (options.reserved[0]): 20 failing ones are reported as
+    unsupported, never guessed, and pass on an engine that allows 32."""
+    import zkemail_rs_amd as z
+    ks = (1, 2, 3, 5, 12)
+    cs = [cases.multi_signature_case(k) for k in ks]
+    got, exp, d1, d2 = run_both(engine, oracle, [c.email for c in cs])
     assert_records_equal(got, exp, [c.name for c in cs], "rounds")
-    assert (got["status"] == 0).all() and [int(x) for x in got["sig_index"]] == [1, 2, 3]
-    c5 = cases.multi_signature_case(5)
-    got5, exp5, _, _ = run_both(engine, oracle, [c5.email])
-    assert int(exp5[0]["status"]) == A.ZKE_OK                       # the reference would pass it
-    assert int(got5[0]["status"]) == A.ZKE_UNSUPPORTED and int(got5[0]["detail"]) == A.D_U_TOO_MANY_SIGS
+    assert (got["status"] == 0).all() and [int(x) for x in got["sig_index"]] == list(ks)
+    for i, c in enumerate(cs):
+        k = len(c.inter["em"])
+        assert bytes(d1.em[i, :k]) == c.inter["em"] == bytes(d2.em[i, :k]), c.name
+        hl = int(exp[i]["canon_header_len"])
+        assert bytes(d1.canon_header[i, :hl]) == bytes(d2.canon_header[i, :hl]), c.name
+    c20 = cases.multi_signature_case(20)
+    got20, exp20, _, _ = run_both(engine, oracle, [c20.email])
+    assert int(exp20[0]["status"]) == A.ZKE_OK                       # the reference would pass it
+    assert int(got20[0]["status"]) == A.ZKE_UNSUPPORTED and int(got20[0]["detail"]) == A.D_U_TOO_MANY_SIGS
+    wide = z.Engine(max_sig_rounds=32)
+    got32 = wide.verify_batch(A.PackedBatch([c20.email] + [c.email for c in cs]))
+    exp32 = oracle.verify_batch(A.PackedBatch([c20.email] + [c.email for c in cs]))
+    assert_records_equal(got32, exp32, None, "32 rounds")
+    assert int(got32[0]["status"]) == A.ZKE_OK and int(got32[0]["sig_index"]) == 20
+    wide.close()
 
 
 def test_repeated_b_value_is_removed_everywhere(engine, oracle):
@@ -363,8 +381,10 @@ def test_device_resident_entry_matches_host_entry():
         engine = z.Engine(0)
         dev = torch.device("cuda", 0)
         inputs, wl, _ = synth.make_regex_workload("dev", 150, 2048, n_header_parts=2, n_body_parts=1, qp_frac=0.05, fail_frac=0.2, seed=21)
+        import cases
+        multi = [cases.multi_signature_case(k).email for k in (1, 3, 6)]        # later signature rounds, no read-back
         for with_regex in (False, True):
-            packed = engine.pack_with_regex(inputs) if with_regex else A.PackedBatch(wl.emails)
+            packed = engine.pack_with_regex(inputs) if with_regex else A.PackedBatch(wl.emails + multi)
             host = engine.verify_batch(packed)
             cb, keep, totals = bench.device_batch(torch, packed, dev)
             extra = {{}}

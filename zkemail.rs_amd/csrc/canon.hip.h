@@ -316,7 +316,8 @@ struct FinArgs { BatchDev b; uint32_t round, max_rounds; uint32_t* pending; uint
 // The verdict of e-mail i, by ONE LANE (64 e-mails per wave at once: the loads of an e-mail's state are a dependent
 // chain of a microsecond or so, which a wave walking its e-mails one after the other would pay 64 times over).
 // rsa_ok: the RSA outcome (EM's shape and digest both fit); ed_ok / ed_key_bad: the Ed25519 stage's.
-__device__ __forceinline__ void verdict_lane(const FinArgs& A, uint32_t i, bool rsa_ok, bool ed_ok, bool ed_key_bad) {
+// Returns true when the e-mail now waits for another signature round (ST_PENDING).
+__device__ __forceinline__ bool verdict_lane(const FinArgs& A, uint32_t i, bool rsa_ok, bool ed_ok, bool ed_key_bad) {
   const BatchDev& B = A.b;
   EmailMeta* M = B.meta + i;
   zke_result* R = B.results + i;
@@ -367,8 +368,8 @@ __device__ __forceinline__ void verdict_lane(const FinArgs& A, uint32_t i, bool 
       if (A.round + 1 < A.max_rounds) {
         if (unsupported_here) M->unsupported = err;
         M->state = ST_PENDING; M->cand_err = err; R->status = ZKE_DKIM_NOT_PASS; R->detail = err;
-        atomicAdd(A.pending, 1u);
-        return;
+        atomicAdd(A.pending, 1u);          // statistics only: the next round runs in this launch (verdict.hip.h)
+        return true;
       }
       status = ZKE_UNSUPPORTED; detail = ZKE_D_U_TOO_MANY_SIGS;
       R->sig_index = M->last_touched_sig;
@@ -386,6 +387,7 @@ __device__ __forceinline__ void verdict_lane(const FinArgs& A, uint32_t i, bool 
 #pragma unroll
     for (int k = 0; k < 8; k++) { ((uint32_t*)R->from_domain_hash)[k] = 0; ((uint32_t*)R->public_key_hash)[k] = 0; }
   }
+  return false;
 }
 
 }  // namespace zke

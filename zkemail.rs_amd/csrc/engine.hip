@@ -33,8 +33,10 @@ namespace {
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
+  uint64_t* generation = nullptr;      // bumped on every (re)allocation, when the owner wants to know
   int ensure(size_t need) {
     if (need <= cap) return 0;
+    if (generation) ++*generation;
     if (p) (void)hipFree(p);
     p = nullptr;
     size_t want = std::max(need + need / 4, (size_t)4096);
@@ -77,6 +79,11 @@ struct Slot {
   DevBuf lanews;   // LaneWs[n]: per-e-mail header table / tag records / tag values of the lane-per-e-mail front end
   DevBuf pending;  // device counters: e-mails that need another signature round
   DevBuf* all[13] = {&meta, &rsa_jobs, &sha_jobs, &rsa_ok, &em_dbg, &scratch_off, &scratch, &clean, &meta2, &scratch2, &parts, &lanews, &pending};
+  // hipGraph replay of a batch's kernel sequence (ZKE_GRAPHS=1).  The graph holds this slot's workspace
+  // pointers, so it is valid only while none of them has been reallocated: `generation` counts reallocations.
+  hipGraphExec_t graph_exec = nullptr;
+  std::vector<uint8_t> graph_key;      // everything the captured launches depend on, byte for byte
+  uint64_t generation = 0;
 };
 
 struct zke_engine {
@@ -103,9 +110,10 @@ struct zke_engine {
   size_t dfa_wave_lds_attr = 0;
   uint64_t batch_key_total = 0;     // key bytes of the batch being run: > 272 per e-mail -> some modulus is above 2048 bits
   int rsa_quad = -1;                // four-lanes-per-signature RSA kernel (rsa_quad.hip.h): -1 by batch size, 0 never, 1 always (ZKE_RSA_QUAD)
-  uint32_t rsa_quad_min = 0;        // -1: batches of at least this many e-mails (ZKE_RSA_QUAD_MIN).  0 since the modexp runs beside
-                                    // SHA-256 (fused.hip.h): its longer chain no longer sits behind the hashes of a small batch
-  uint32_t rsa_oct_min = 0;         // ... for the eight-lane form of moduli above 2048 bits (ZKE_RSA_OCT_MIN)
+  uint32_t rsa_quad_min = 256;      // -1: batches of at least this many e-mails (ZKE_RSA_QUAD_MIN).  Low since the modexp runs beside
+                                    // SHA-256 (fused.hip.h): its longer chain no longer sits behind the hashes of a small batch; a
+                                    // handful of e-mails is still answered sooner by the short chain of one signature per wave
+  uint32_t rsa_oct_min = 128;       // ... for the eight-lane form of moduli above 2048 bits (ZKE_RSA_OCT_MIN)
   int sha_pair = -1;                // two-wave SHA-256 kernel: -1 by launch size, 0 never, 1 always (ZKE_SHA_PAIR)
   bool wave_parse = true;           // front end: one e-mail per wavefront (parse.hip.h); ZKE_LANE_PARSE=1 selects the
                                     // one-e-mail-per-lane variant (front.hip.h), see DESIGN.md §3
@@ -113,8 +121,8 @@ struct zke_engine {
   uint32_t fuse_canon = 1;          // body canonicalisation inside the wave-per-e-mail front end (ZKE_NO_FUSE_CANON=1: own launch)
   uint32_t debug_skip_ed = 0;       // ZKE_DEBUG_SKIP_ED: ablation, drops the Ed25519 stage launch (Ed25519 e-mails then fail)
   uint32_t debug_parse_stop = 0;    // ZKE_DEBUG_PARSE_STOP: timing experiments (results are then meaningless)
-  uint32_t max_sig_rounds = 4;      // host mode: upper bound, rounds are added only while e-mails are pending
-  uint32_t device_mode_rounds = 1;  // device mode: fixed (no read-back)
+  uint32_t max_sig_rounds = 16;     // same-domain signatures tried per e-mail before ZKE_D_U_TOO_MANY_SIGS (options.reserved[0], up to 256)
+  bool use_graphs = false;          // ZKE_GRAPHS=1: device-mode batches replay a captured hipGraph when the same descriptor comes again
   uint32_t key_cache_replicas = 1;  // ZKE_KEY_CACHE_REPLICAS (experiment): slot k uses copy k % replicas of the key cache
 };
 
@@ -189,11 +197,13 @@ Slot* new_slot(zke_engine* e) {
             hipEventCreateWithFlags(&w->done, hipEventDisableTiming) == hipSuccess;
   for (auto& ev : w->ev) ok = ok && hipEventCreate(&ev) == hipSuccess;
   if (!ok) { e->err = "slot stream / event creation"; delete w; return nullptr; }
+  for (auto* b : w->all) b->generation = &w->generation;
   return w;
 }
 void free_slot(Slot* w) {
   if (!w) return;
   if (w->stream) (void)hipStreamSynchronize(w->stream);
+  if (w->graph_exec) (void)hipGraphExecDestroy(w->graph_exec);
   for (auto* b : w->all) b->release();
   for (auto& ev : w->ev) if (ev) (void)hipEventDestroy(ev);
   if (w->done) (void)hipEventDestroy(w->done);
@@ -306,8 +316,8 @@ int zke_engine_create(const zke_options* opt, zke_engine** out) {
       return ZKE_E_NOMEM;
     }
   }
-  if (opt && opt->reserved[0]) e->max_sig_rounds = std::min<uint32_t>(opt->reserved[0], 8);
-  if (opt && opt->reserved[1]) e->device_mode_rounds = std::min<uint32_t>(opt->reserved[1], 8);
+  if (opt && opt->reserved[0]) e->max_sig_rounds = std::min<uint32_t>(opt->reserved[0], ZKE_MAX_HEADERS);
+  if (const char* g = getenv("ZKE_GRAPHS")) e->use_graphs = atoi(g) != 0;
   if (getenv("ZKE_LANE_PARSE")) e->wave_parse = false;
   if (const char* st = getenv("ZKE_SHA_TILE")) e->sha_tile = atoi(st);
   if (const char* sp = getenv("ZKE_SHA_PAIR")) e->sha_pair = atoi(sp);

@@ -752,11 +752,11 @@ __device__ __forceinline__ void canon_body_wave(const BatchDev& B, uint32_t i, u
 
 __device__ const uint8_t DKIM_NAME[14] = {'D', 'K', 'I', 'M', '-', 'S', 'i', 'g', 'n', 'a', 't', 'u', 'r', 'e'};
 
-__global__ __launch_bounds__(64, 6) void parse_kernel(ParseArgs A) {
-  __shared__ ParseLds L;
+// The front end of e-mail i by the calling wave (L: the wave's LDS image).  parse_kernel runs it for every e-mail of a
+// batch (round 0, and mode 1); the verdict launch runs it again, round by round, for the rare e-mail whose candidate
+// signature failed while a later same-domain signature is still untried (verdict.hip.h).
+__device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i, ParseLds& L) {
   const BatchDev& B = A.b;
-  const uint32_t i = blockIdx.x;
-  if (i >= B.n) return;
   const int lane = lane_id();
   EmailMeta* M = B.meta + i;
   zke_result* R = B.results + i;
@@ -1097,13 +1097,20 @@ __global__ __launch_bounds__(64, 6) void parse_kernel(ParseArgs A) {
   if (lane == 0) {
     M->state = ST_CAND;
     // an Ed25519 candidate leaves the RSA job inactive; ed25519_email_kernel verifies it
-    const uint32_t jf = (cand_flags & ZKE_F_ED25519) ? 0u : (RSA_F_ACTIVE | ((cand_flags & ZKE_F_SHA1) ? (uint32_t)RSA_F_SHA1 : 0u) | (M->rsa_route & (RSA_F_QUAD | RSA_F_OCT)));
+    const uint32_t jf = (cand_flags & ZKE_F_ED25519) ? 0u : (RSA_F_ACTIVE | ((cand_flags & ZKE_F_SHA1) ? (uint32_t)RSA_F_SHA1 : 0u) |
+                                                                  (A.route_mask ? M->rsa_route & (RSA_F_QUAD | RSA_F_OCT) : 0u));
     J->flags = jf;
     M->em_ok = 0;
     if ((jf & RSA_F_ACTIVE) && !(jf & (RSA_F_QUAD | RSA_F_OCT)) && A.wave_list) A.wave_list[atomicAdd(A.wave_count, 1u)] = i;
   }
   // ---- body canonicalisation of the candidate (cfdkim hash::compute_body_hash), same wave, no launch boundary
   if (A.fuse_canon) canon_body_wave(B, i, 0, cand_flags, body_off, raw.len - body_off, cand_len_tag, L.stage);   // parsing is over: the staged head is dead
+}
+
+__global__ __launch_bounds__(64, 6) void parse_kernel(ParseArgs A) {
+  __shared__ ParseLds L;
+  if (blockIdx.x >= A.b.n) return;
+  parse_email(A, blockIdx.x, L);
 }
 
 // CSR (blob, off[n+1]) -> ShaJob list with digests packed 32 B apart (building-block entry point)

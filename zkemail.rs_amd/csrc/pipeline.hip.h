@@ -60,11 +60,11 @@ int raise_dfa_lds_attrs(zke_engine* e, size_t lds) {
   return 0;
 }
 
-// The device pipeline.  Every pointer in `in` / out_dev is device memory.
-// Signature rounds [round_begin, round_end) of verify_email_with_key run here; the regex stage runs when
-// `with_regex_stage` is set (after the last round the caller intends to run).
+// The device pipeline.  Every pointer in `in` / out_dev is device memory.  Three launches — front end, hash / modexp
+// stage, Ed25519 + verdict (which also runs the later signature rounds of the rare e-mail that needs them) — and, for
+// verify_email_with_regex, the regex stage behind them.
 int run_device_pipeline(zke_engine* e, Slot& w, const zke_batch* in, uint64_t raw_total, zke_result* out_dev, hipStream_t s,
-                        bool want_em, uint32_t round_begin, uint32_t round_end, uint32_t max_rounds, bool with_regex_stage) {
+                        bool want_em) {
   const uint32_t n = in->n;
   if (n == 0) return 0;
   const uint32_t n_pad = (n + 63) & ~63u;
@@ -95,11 +95,11 @@ int run_device_pipeline(zke_engine* e, Slot& w, const zke_batch* in, uint64_t ra
   B.pending = w.pending.as<uint32_t>();
   B.meta_verify = nullptr;
 
-  const uint32_t rounds = max_rounds;
+  const uint32_t rounds = std::max<uint32_t>(1, e->max_sig_rounds);
   // an RSA-2048 key is 270 bytes of DER: a batch whose keys average more holds some larger modulus
   const uint32_t route_mask = rsa_route_mask(e, n, e->batch_key_total > (uint64_t)n * 272);
-  for (uint32_t round = round_begin; round < round_end; round++) {
-    // front end: parse, candidate signature, header-hash preimage, canonical body, RSA routing (parse.hip.h)
+  {
+    const uint32_t round = 0;
     uint32_t* wave_count = e->wave_parse ? w.pending.as<uint32_t>() + 2 : nullptr;      // the lane-per-e-mail front end keeps no list
     uint32_t* wave_list = e->wave_parse ? w.rsa_ok.as<uint32_t>() : nullptr;
     if (e->wave_parse) {
@@ -109,25 +109,27 @@ int run_device_pipeline(zke_engine* e, Slot& w, const zke_batch* in, uint64_t ra
       FrontArgs fa{B, w.lanews.as<LaneWs>(), round, 0, e->debug_parse_stop};
       hipLaunchKernelGGL(front_kernel, dim3((n + 63) / 64), dim3(64), FRONT_LDS_BYTES, s, fa);
     }
-    if (round == 0) tm.mark();
+    tm.mark();
     if (!(e->wave_parse && e->fuse_canon)) {      // the wave-per-e-mail front end canonicalises the body itself
       CanonArgs ca{B, 0};
       hipLaunchKernelGGL(canon_body_kernel, dim3(n), dim3(64), 0, s, ca);
     }
-    if (round == 0) tm.mark();
+    tm.mark();
     // hash / modexp stage: the four SHA-256 jobs and the RSA operation of every e-mail, one launch (fused.hip.h)
-    if ((r = launch_hash_modexp(e, B.sha, 4 * n_pad, B.rsa, n, B.meta, want_em ? w.em_dbg.as<uint8_t>() : nullptr, route_mask,
+    static const int x_skip = getenv("ZKE_DEBUG_SKIP_LAUNCH") ? atoi(getenv("ZKE_DEBUG_SKIP_LAUNCH")) : 0;   // ablation: bit 0 stage, bit 1 verdict
+    if (!(x_skip & 1) && (r = launch_hash_modexp(e, B.sha, 4 * n_pad, B.rsa, n, B.meta, want_em ? w.em_dbg.as<uint8_t>() : nullptr, route_mask,
                                 wave_count, wave_list, s)))
       return r;
-    if (round == 0) tm.mark();
+    tm.mark();
     // Ed25519 stage + verdicts (verdict.hip.h): bh compare, EM digest against the header hash, status / detail, pending counter
-    EdVerdictArgs va{FinArgs{B, round, rounds, w.pending.as<uint32_t>(), e->debug_skip_rsa}, e->debug_skip_ed, wave_count};
-    hipLaunchKernelGGL(ed_verdict_kernel, dim3((n + 63) / 64), dim3(64), 0, s, va);
-    if (round == 0) { tm.mark(); tm.mark(); }      // sha_us = the hash / modexp launch, rsa_us = the Ed25519 + verdict launch (finalize_us reads 0)
+    EdVerdictArgs va{FinArgs{B, round, rounds, w.pending.as<uint32_t>(), e->debug_skip_rsa}, e->debug_skip_ed, wave_count,
+                     e->key_cache.as<KeyCacheEntry>(), want_em ? w.em_dbg.as<uint8_t>() : nullptr};
+    if (!(x_skip & 2)) hipLaunchKernelGGL(ed_verdict_kernel, dim3((n + 63) / 64), dim3(64), 0, s, va);
+    tm.mark(); tm.mark();      // sha_us = the hash / modexp launch, rsa_us = the Ed25519 + verdict launch (finalize_us reads 0)
   }
   HIPCHK(e, hipGetLastError());
 
-  if (in->with_regex && with_regex_stage) {
+  if (in->with_regex) {
     // canonicalize_signed_email (circuits.rs:34-35): first DKIM-Signature header, own scratch unless it is the verified one
     BatchDev B2 = B;
     B2.meta = w.meta2.as<EmailMeta>();
@@ -431,8 +433,6 @@ int zke_verify_batch_device(zke_engine* e, const zke_batch* in, uint64_t raw_tot
   // the part-id lists are small host arrays even in device mode
   e->host_hdr_ids.assign(in->header_part_ids, in->header_part_ids + (in->with_regex ? in->n_header_parts : 0));
   e->host_body_ids.assign(in->body_part_ids, in->body_part_ids + (in->with_regex ? in->n_body_parts : 0));
-  // device mode runs a fixed number of signature rounds (options.reserved[1], default 1) without reading anything back
-  const uint32_t rounds = e->device_mode_rounds;
   // Submission slots are taken round-robin: with S slots, S batches are in flight before a workspace is reused.
   const uint32_t slot = e->next_slot;
   e->next_slot = (slot + 1) % (uint32_t)e->slots.size();
@@ -440,8 +440,73 @@ int zke_verify_batch_device(zke_engine* e, const zke_batch* in, uint64_t raw_tot
   Slot& w = *e->slots[slot];
   hipStream_t s = stream ? (hipStream_t)stream : w.stream;
   if (int r = acquire_slot(e, w, s)) return r;
-  // Launched eagerly: four kernels per batch (five or six when the lane-group RSA kernels take part: batches >= 2 048).
-  if (int r = run_device_pipeline(e, w, in, raw_total, out_dev, s, false, 0, rounds, rounds, true)) return r;
+  if (!e->use_graphs || e->timing) {
+    // Launched eagerly: three kernels per signature round (front end, hash / modexp stage, Ed25519 + verdict)
+    if (int r = run_device_pipeline(e, w, in, raw_total, out_dev, s, false)) return r;
+    return release_slot(e, w, s);
+  }
+  // hipGraph replay (opt-in).  A service re-submits batches that live in the same staging buffers: the second time a
+  // slot sees a descriptor byte for byte — input pointers and sizes, output pointer, part ids, rounds, key-size hint —
+  // its kernel sequence is captured, and replayed from then on.  The key also holds the slot's workspace generation: a
+  // graph bakes in the workspace pointers, and a batch that regrew a buffer in between (DevBuf::ensure frees and
+  // reallocates) would leave them dangling.  Nothing in the submit path calls hipMalloc / hipFuncSetAttribute once the
+  // workspaces are reserved, so the capture contains kernel nodes only.
+  std::vector<uint8_t> key(sizeof(zke_batch) + 5 * sizeof(uint64_t) + 4 * (e->host_hdr_ids.size() + e->host_body_ids.size()));
+  {
+    zke_batch kb = *in;
+    kb.header_part_ids = nullptr; kb.body_part_ids = nullptr;          // host arrays: compared by content below
+    uint8_t* p = key.data();
+    memset(p, 0, key.size());
+    memcpy(p, &kb.n, sizeof kb.n);                                     // field by field: the struct's padding is not copied
+    size_t o = 8;
+    const void* ptrs[] = {kb.raw_blob, kb.raw_off, kb.domain_blob, kb.domain_off, kb.key_blob, kb.key_off, kb.key_type, kb.ext_null,
+                          kb.cap_off, kb.cap_str_off, kb.cap_blob, out_dev, s};
+    for (const void* q : ptrs) { memcpy(p + o, &q, sizeof q); o += sizeof q; }
+    const uint64_t nums[] = {raw_total, key_total, ((uint64_t)kb.with_regex << 32) | e->max_sig_rounds, ((uint64_t)kb.n_header_parts << 32) | kb.n_body_parts,
+                             w.generation};
+    (void)o;
+    uint8_t* tail = p + sizeof(zke_batch);
+    memcpy(tail, nums, sizeof nums);
+    tail += sizeof nums;
+    if (!e->host_hdr_ids.empty()) memcpy(tail, e->host_hdr_ids.data(), 4 * e->host_hdr_ids.size());
+    tail += 4 * e->host_hdr_ids.size();
+    if (!e->host_body_ids.empty()) memcpy(tail, e->host_body_ids.data(), 4 * e->host_body_ids.size());
+  }
+  static_assert(8 + 13 * sizeof(void*) <= sizeof(zke_batch), "graph key layout");
+  if (w.graph_exec && key == w.graph_key) {
+    HIPCHK(e, hipGraphLaunch(w.graph_exec, s));
+    return release_slot(e, w, s);
+  }
+  if (w.graph_exec) { (void)hipGraphExecDestroy(w.graph_exec); w.graph_exec = nullptr; }
+  if (key != w.graph_key) {               // first sighting: run eagerly (this is also what sizes the workspaces)
+    if (int r = run_device_pipeline(e, w, in, raw_total, out_dev, s, false)) return r;
+    // the generation may have moved: remember the key as it is now, so that an identical second call captures
+    const uint64_t gen = w.generation;
+    memcpy(key.data() + sizeof(zke_batch) + 4 * sizeof(uint64_t), &gen, sizeof gen);
+    w.graph_key = key;
+    return release_slot(e, w, s);
+  }
+  hipGraph_t g = nullptr;
+  HIPCHK(e, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  const int r = run_device_pipeline(e, w, in, raw_total, out_dev, s, false);
+  const hipError_t ce = hipStreamEndCapture(s, &g);
+  if (r || ce != hipSuccess || !g) {
+    if (g) (void)hipGraphDestroy(g);
+    e->use_graphs = false;                // capture is an optimisation only: fall back to eager launches
+    if (r) return r;
+    if (int r2 = run_device_pipeline(e, w, in, raw_total, out_dev, s, false)) return r2;
+    return release_slot(e, w, s);
+  }
+  hipGraphExec_t ge = nullptr;
+  const hipError_t ie = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (ie != hipSuccess || !ge) {
+    e->use_graphs = false;
+    if (int r2 = run_device_pipeline(e, w, in, raw_total, out_dev, s, false)) return r2;
+    return release_slot(e, w, s);
+  }
+  w.graph_exec = ge;
+  HIPCHK(e, hipGraphLaunch(w.graph_exec, s));
   return release_slot(e, w, s);
 }
 
@@ -509,30 +574,8 @@ int zke_verify_batch(zke_engine* e, const zke_batch* in, zke_result* out, zke_de
   dv.cap_blob = caps ? e->in_cap_blob.as<uint8_t>() : nullptr;
   e->host_hdr_ids.assign(in->header_part_ids, in->header_part_ids + (in->with_regex ? in->n_header_parts : 0));
   e->host_body_ids.assign(in->body_part_ids, in->body_part_ids + (in->with_regex ? in->n_body_parts : 0));
-  // Signature rounds: round r tries every e-mail's r-th same-domain signature.  Almost every e-mail is decided
-  // in round 0; the device counts the undecided ones and the host adds rounds only while that count is non-zero.
-  const uint32_t max_rounds = std::max<uint32_t>(1, e->max_sig_rounds);
   const bool want_em = dbg && dbg->em;
-  uint32_t round = 0;
-  for (;;) {
-    const bool last_possible = round + 1 >= max_rounds;
-    // the regex stage must follow the final verdicts: run it with this round only if no further round can follow
-    if ((r = run_device_pipeline(e, w, &dv, raw_total, e->results.as<zke_result>(), s, want_em, round, round + 1, max_rounds,
-                                 last_possible)))
-      return r;
-    if (last_possible) break;
-    uint32_t pending = 0;
-    HIPCHK(e, hipMemcpyAsync(&pending, w.pending.p, 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(e, hipStreamSynchronize(s));
-    if (pending == 0) {
-      if (in->with_regex && (r = run_device_pipeline(e, w, &dv, raw_total, e->results.as<zke_result>(), s, want_em, round + 1,
-                                                     round + 1, max_rounds, true)))
-        return r;
-      break;
-    }
-    HIPCHK(e, hipMemsetAsync(w.pending.p, 0, 8, s));
-    round++;
-  }
+  if ((r = run_device_pipeline(e, w, &dv, raw_total, e->results.as<zke_result>(), s, want_em))) return r;
   if (e->timing) (void)hipEventRecord(d0, s);
   HIPCHK(e, hipMemcpyAsync(out, e->results.p, (size_t)n * sizeof(zke_result), hipMemcpyDeviceToHost, s));
   HIPCHK(e, hipStreamSynchronize(s));

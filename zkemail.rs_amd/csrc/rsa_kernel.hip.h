@@ -55,14 +55,14 @@ __device__ __forceinline__ bool emsa_tail_ok(uint32_t tail_of_lane, const uint32
 //   hash_base != nullptr: the building-block entry point — the digest is at hand, ok_out[job] = full verification.
 // em_out (optional): EM big-endian, 512 B slots, right-aligned like RsaJob.sig.
 template <int NL>
-__device__ __forceinline__ void rsa_wave(const RsaJob* __restrict__ jobs, uint32_t job,
+__device__ __forceinline__ bool rsa_wave(const RsaJob* __restrict__ jobs, uint32_t job,
                                          const uint8_t* __restrict__ hash_base, size_t hash_stride,
                                          uint32_t* __restrict__ ok_out, uint8_t* __restrict__ em_out,
                                          KeyCacheEntry* cache, EmailMeta* meta, uint32_t debug_skip) {
   const int lane = threadIdx.x & 63;
   const RsaJob* J = jobs + job;
   const uint32_t flags = J->flags, k = J->k, bits = J->bits;
-  if (flags & (RSA_F_QUAD | RSA_F_OCT)) return;
+  if (flags & (RSA_F_QUAD | RSA_F_OCT)) return false;
 
   Big<NL> nn, s;
 #pragma unroll
@@ -189,15 +189,16 @@ __device__ __forceinline__ void rsa_wave(const RsaJob* __restrict__ jobs, uint32
     }
     if (NL == 1) *(uint32_t*)(em_out + (size_t)job * 512 + 4 * lane) = 0;   // upper half of the slot
   }
+  return ok != 0;               // full verification: meaningful when hash_base was given
 }
 
 // a wave picks the one-limb-per-lane (<= 2048 bits) or two-limbs-per-lane path from its job's modulus size
-__device__ __forceinline__ void rsa_wave_any(const RsaJob* __restrict__ jobs, uint32_t job, const uint8_t* __restrict__ hash_base,
+__device__ __forceinline__ bool rsa_wave_any(const RsaJob* __restrict__ jobs, uint32_t job, const uint8_t* __restrict__ hash_base,
                                              size_t hash_stride, uint32_t* __restrict__ ok_out, uint8_t* __restrict__ em_out,
                                              KeyCacheEntry* cache, EmailMeta* meta, uint32_t debug_skip) {
   const uint32_t bits = __builtin_amdgcn_readfirstlane(jobs[job].bits);
-  if (bits <= 2048) rsa_wave<1>(jobs, job, hash_base, hash_stride, ok_out, em_out, cache, meta, debug_skip);
-  else rsa_wave<2>(jobs, job, hash_base, hash_stride, ok_out, em_out, cache, meta, debug_skip);
+  if (bits <= 2048) return rsa_wave<1>(jobs, job, hash_base, hash_stride, ok_out, em_out, cache, meta, debug_skip);
+  return rsa_wave<2>(jobs, job, hash_base, hash_stride, ok_out, em_out, cache, meta, debug_skip);
 }
 
 // Stand-alone launch (launches too large for the fused kernel, the building-block entry point): grid = n, blockDim = 64.

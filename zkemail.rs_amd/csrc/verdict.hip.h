@@ -13,9 +13,96 @@
 
 namespace zke {
 
-struct EdVerdictArgs { FinArgs fin; uint32_t skip_ed; uint32_t* wave_count; };   // wave_count: the hash / modexp stage's job list is consumed — reset for the next round
+struct EdVerdictArgs {
+  FinArgs fin; uint32_t skip_ed;
+  uint32_t* wave_count;      // the hash / modexp stage's job list is consumed: reset for the next batch
+  KeyCacheEntry* cache;      // later signature rounds: per-key Montgomery constants
+  uint8_t* em_out;           // parity intermediates (nullptr in production)
+};
+
+// SHA-256 / SHA-1 of one message by ONE LANE (later signature rounds only: two messages per e-mail, a rare path; the
+// batched kernels of sha256.hip.h are the hot one).  FIPS 180-4; the digest goes to j.dst as the batch kernels write it.
+__device__ __forceinline__ void sha_lane(const ShaJob& j) {
+  if (!j.dst) return;
+  const uint8_t* src = (const uint8_t*)j.src;
+  const uint32_t len = j.len, nblk = (len + 9 + 63) >> 6;
+  uint32_t st[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+  if (j.pad) { st[0] = 0x67452301; st[1] = 0xEFCDAB89; st[2] = 0x98BADCFE; st[3] = 0x10325476; st[4] = 0xC3D2E1F0; st[5] = st[6] = st[7] = 0; }
+  typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+  for (uint32_t b = 0; b < nblk; b++) {
+    uint32_t w[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const uint32_t o = 64 * b + 4 * k;
+      uint32_t v;
+      if (o + 4 <= len) v = __builtin_bswap32(*(const u32_unaligned*)(src + o));
+      else {
+        v = 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          const uint32_t q = o + t;
+          const uint32_t c = q < len ? (uint32_t)src[q] : (q == len ? 0x80u : 0u);
+          v |= c << (24 - 8 * t);
+        }
+      }
+      w[k] = v;
+    }
+    if (b == nblk - 1) { const uint64_t bits = (uint64_t)len * 8; w[14] = (uint32_t)(bits >> 32); w[15] = (uint32_t)bits; }
+    if (j.pad) sha1_compress(st, w); else sha256_compress(st, w);
+  }
+  uint32_t* out = (uint32_t*)j.dst;
+#pragma unroll
+  for (int k = 0; k < 8; k++) out[k] = (j.pad && k >= 5) ? 0u : __builtin_bswap32(st[k]);
+}
+
+// what one lane stored, the other lanes of this wave read back: past this CU's L1 (rare paths only: an agent-scope
+// fence is an L2 write-back / invalidate on this chip)
+__device__ __forceinline__ void wave_publish() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+// Later signature rounds of e-mail e, inside the verdict launch, by the whole wave: cfdkim's verify_email_with_key tries
+// the same-domain signatures one after the other until one passes (behind core/src/email.rs:31-33).  Round 0 of every
+// e-mail runs in the batch's three launches; an e-mail whose round-0 candidate failed while another candidate is left is
+// rare, and giving it launches of its own would charge every batch for them: here it costs a ballot per wave.
+__device__ __forceinline__ void later_rounds(const EdVerdictArgs& A, uint32_t e, ParseLds& L) {
+  const BatchDev& B = A.fin.b;
+  const int lane = threadIdx.x & 63;
+  EmailMeta* M = B.meta + e;
+  zke_result* R = B.results + e;
+  for (uint32_t round = A.fin.round + 1; round < A.fin.max_rounds; round++) {
+    wave_publish();                                     // the verdict lane's EmailMeta / record stores
+    ParseArgs pa{B, round, 0, 0, 1, nullptr, 0, nullptr, nullptr};
+    parse_email(pa, e, L);
+    wave_publish();                                     // the front end's jobs, preimage and canonical body
+    FinArgs fin = A.fin;
+    fin.round = round;
+    bool rsa_ok = false, ed_ok = false;
+    if (M->state == ST_CAND) {
+      if (lane < 2) sha_lane(B.sha[(size_t)lane * B.n_pad + e]);      // kind 0: body, kind 1: header preimage
+      wave_publish();
+      if (M->flags & ZKE_F_ED25519) {
+        uint32_t r = 0;
+        if (lane == 0) {
+          const RsaJob* J = B.rsa + e;
+          r = ed25519_verify_lane(B.key + B.key_off[e], R->header_hash, 32, J->sig + (512 - 64), J->sig_len == 64);
+          M->ed_ok = (r == 2) ? 1u : 0u;
+        }
+        ed_ok = __builtin_amdgcn_readfirstlane(r) == 2;
+      } else {
+        rsa_ok = rsa_wave_any(B.rsa, e, reinterpret_cast<const uint8_t*>(B.results) + offsetof(zke_result, header_hash), sizeof(zke_result),
+                              nullptr, A.em_out, A.cache, B.meta, A.fin.debug_skip_rsa);
+      }
+    }
+    uint32_t again = 0;
+    if (lane == 0) again = verdict_lane(fin, e, rsa_ok, ed_ok, M->ed_key_bad != 0) ? 1u : 0u;
+    if (!__builtin_amdgcn_readfirstlane(again)) return;
+  }
+}
 
 __global__ __launch_bounds__(64) void ed_verdict_kernel(EdVerdictArgs A) {
+  __shared__ ParseLds L;
   const BatchDev& B = A.fin.b;
   const int lane = threadIdx.x & 63;
   const uint32_t base = blockIdx.x * 64, i = base + (uint32_t)lane;
@@ -39,6 +126,7 @@ __global__ __launch_bounds__(64) void ed_verdict_kernel(EdVerdictArgs A) {
     }
   }
   // ---- verdicts, lane per e-mail
+  bool again = false;
   if (i < B.n) {
     const EmailMeta* M = B.meta + i;
     bool rsa_ok = false;
@@ -49,8 +137,10 @@ __global__ __launch_bounds__(64) void ed_verdict_kernel(EdVerdictArgs A) {
       rsa_ok = true;
       for (uint32_t l = 0; l < hl4; l++) rsa_ok = rsa_ok && M->em_tail[l] == __builtin_bswap32(hw[hl4 - 1 - l]);
     }
-    verdict_lane(A.fin, i, rsa_ok, ed_ok != 0, ed_bad != 0);
+    again = verdict_lane(A.fin, i, rsa_ok, ed_ok != 0, ed_bad != 0);
   }
+  // ---- later signature rounds of the e-mails that are still undecided, one at a time with the whole wave
+  for (uint64_t pend = __ballot(again); pend; pend &= pend - 1) later_rounds(A, base + (uint32_t)__builtin_ctzll(pend), L);
 }
 
 }  // namespace zke

@@ -102,12 +102,13 @@ class Engine:
     """One engine per GPU (``zke_engine``): owns the device workspace, the stream and the
     registered DFA tables."""
 
-    def __init__(self, device: int = -1):
+    def __init__(self, device: int = -1, max_sig_rounds: int = 0):
         self.lib = load_library()
         if not self.lib.zke_device_available():
             raise EngineError("no HIP device visible; the engine has no CPU path")
         opt = A.zke_options()
         opt.device = device
+        opt.reserved[0] = max_sig_rounds          # same-domain signatures tried per e-mail (0 = the default, 16)
         h = C.c_void_p()
         rc = self.lib.zke_engine_create(C.byref(opt), C.byref(h))
         if rc != 0:
