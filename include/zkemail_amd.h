@@ -293,6 +293,18 @@ int zke_ed25519_verify_batch(zke_engine* e, const uint8_t* keys, const uint8_t* 
 int zke_sha256_batch_device(zke_engine* e, const uint8_t* msg_blob_dev, const uint64_t* off_dev,
                             uint32_t n, uint8_t* digests_dev, void* stream);
 
+/* Solidity ABI encoding of a verifier output — what VerificationOutput::from_parts(email, matches).abi_encode()
+ * returns (core/src/io.rs:28-44): abi.encode of
+ *     struct SolEmailOutput          { bytes32 from_domain_hash; bytes32 public_key_hash; string[] external_inputs; }
+ *     struct SolEmailWithRegexOutput { SolEmailOutput email; string[] matches; }               (core/src/io.rs:5-16)
+ * with_matches == 0: EmailOnly; != 0: WithRegex (matches may then be empty).  Strings are UTF-8 bytes with lengths.
+ * Pure host code, no engine and no GPU.  Writes *out_len = the encoding's size; returns ZKE_E_NOMEM (nothing written)
+ * when out_cap is smaller — call with out == NULL, out_cap == 0 to size the buffer. */
+int zke_abi_encode(const uint8_t* from_domain_hash /*[32]*/, const uint8_t* public_key_hash /*[32]*/,
+                   const uint8_t* const* external_inputs, const size_t* external_input_lens, uint32_t n_external_inputs,
+                   uint32_t with_matches, const uint8_t* const* matches, const size_t* match_lens, uint32_t n_matches,
+                   uint8_t* out, size_t out_cap, size_t* out_len);
+
 /* Library / build identification. */
 const char* zke_version(void);
 /* 1 if a HIP device is usable from this process, else 0 (never falls back to a CPU path). */

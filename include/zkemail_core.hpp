@@ -59,6 +59,36 @@ struct EmailWithRegexVerifierOutput {      // structs.rs:72-75
 
 struct EngineError : std::runtime_error { using std::runtime_error::runtime_error; };
 
+// core/src/io.rs:18-44: the on-the-wire form of the witness (Solidity abi.encode of SolEmailOutput /
+// SolEmailWithRegexOutput), through the C entry point zke_abi_encode.
+struct VerificationOutput {
+  EmailVerifierOutput email;
+  std::optional<std::vector<std::string>> matches;      // nullopt: EmailOnly; a value: WithRegex
+  static VerificationOutput from_parts(EmailVerifierOutput email, std::optional<std::vector<std::string>> matches) {   // io.rs:28-33
+    return VerificationOutput{std::move(email), std::move(matches)};
+  }
+  std::vector<uint8_t> abi_encode() const {                                                                                // io.rs:35-44
+    if (email.from_domain_hash.size() != 32 || email.public_key_hash.size() != 32)
+      throw std::length_error("hashes must be 32 bytes");                                                                // io.rs:49-50 try_into().unwrap()
+    auto table = [](const std::vector<std::string>& v, std::vector<const uint8_t*>& p, std::vector<size_t>& l) {
+      for (const auto& s : v) { p.push_back(reinterpret_cast<const uint8_t*>(s.data())); l.push_back(s.size()); }
+    };
+    std::vector<const uint8_t*> p1, p2;
+    std::vector<size_t> l1, l2;
+    table(email.external_inputs, p1, l1);
+    if (matches) table(*matches, p2, l2);
+    size_t need = 0;
+    auto call = [&](uint8_t* out, size_t cap) {
+      return zke_abi_encode(email.from_domain_hash.data(), email.public_key_hash.data(), p1.data(), l1.data(), (uint32_t)p1.size(),
+                            matches ? 1u : 0u, p2.data(), l2.data(), (uint32_t)p2.size(), out, cap, &need);
+    };
+    if (int rc = call(nullptr, 0)) throw EngineError("zke_abi_encode: " + std::to_string(rc));
+    std::vector<uint8_t> out(need);
+    if (int rc = call(out.data(), out.size())) throw EngineError("zke_abi_encode: " + std::to_string(rc));
+    return out;
+  }
+};
+
 // The reference would have panicked here.
 struct VerifyPanic : std::runtime_error {
   uint32_t status, detail;

@@ -1,6 +1,7 @@
 // Exercises include/zkemail_core.hpp (the C++ mirror of zkemail_core's API) end to end.
 // usage: mirror_test <raw.eml> <key.der> <from_domain> [fwd.dfa bwd.dfa capture]
-// prints "OK <from_domain_hash hex> <public_key_hash hex> [matches...]" or "PANIC <status> <detail>"
+// prints "OK <from_domain_hash hex> <public_key_hash hex> [matches...]" or "PANIC <status> <detail>", and on success a
+// second line "ABI <hex>": VerificationOutput::from_parts(..).abi_encode() (core/src/io.rs:28-44)
 #include <cstdio>
 #include <fstream>
 #include <iterator>
@@ -27,10 +28,14 @@ int main(int argc, char** argv) {
       auto out = zkemail::verify_email_with_regex(in);
       std::printf("OK "); hex(out.email.from_domain_hash); std::printf(" "); hex(out.email.public_key_hash);
       for (auto& m : out.regex_matches) std::printf(" [%s]", m.c_str());
+      std::printf("\nABI ");
+      hex(zkemail::VerificationOutput::from_parts(out.email, out.regex_matches).abi_encode());
       std::printf("\n");
     } else {
       auto out = zkemail::verify_email(em);
-      std::printf("OK "); hex(out.from_domain_hash); std::printf(" "); hex(out.public_key_hash); std::printf("\n");
+      std::printf("OK "); hex(out.from_domain_hash); std::printf(" "); hex(out.public_key_hash); std::printf("\nABI ");
+      hex(zkemail::VerificationOutput::from_parts(out, std::nullopt).abi_encode());
+      std::printf("\n");
     }
   } catch (const zkemail::VerifyPanic& p) {
     std::printf("PANIC %u %u\n", p.status, p.detail);

@@ -29,3 +29,26 @@ def test_with_regex_roundtrip_and_layout():
     assert out.email == e and out.regex_matches == ["alice", "hello world"]
     assert len(enc) % 32 == 0
     assert ae.abi_decode(ae.abi_encode(e, [])).regex_matches == []
+
+
+def test_c_entry_point_matches_the_python_encoder():
+    """zke_abi_encode (include/zkemail_amd.h; core/src/io.rs:28-44) — the encoder a host linking the C-ABI uses — gives
+    the bytes of the Python encoder on the hand-laid vector and on seeded random outputs (empty lists, empty strings,
+    lengths around the 32-byte padding boundary, non-ASCII); it loads and runs without a GPU."""
+    import numpy as np
+    from zkemail_rs_amd import engine as eng
+    e = EmailVerifierOutput(b"\x11" * 32, b"\x22" * 32, ["name", "value-longer-than-32-bytes-0123456789abcdef"])
+    assert eng.abi_encode_native(e) == ae.abi_encode(e)
+    rng = np.random.default_rng(5)
+
+    def rs():
+        n = int(rng.choice([0, 1, 5, 31, 32, 33, 64, 100]))
+        return "".join(chr(int(c)) for c in rng.choice([0x61, 0x7a, 0x20, 0xe9, 0x4e2d, 0x1f600], size=n))
+    for k in range(200):
+        eo = EmailVerifierOutput(bytes(rng.integers(0, 256, 32, dtype=np.uint8)), bytes(rng.integers(0, 256, 32, dtype=np.uint8)),
+                                 [rs() for _ in range(int(rng.integers(0, 5)) * 2)])
+        ms = None if k % 3 == 0 else [rs() for _ in range(int(rng.integers(0, 4)))]
+        want = ae.abi_encode(eo, ms)
+        assert eng.abi_encode_native(eo, ms) == want, k
+        back = ae.abi_decode(want)
+        assert (back == eo) if ms is None else (back.email == eo and back.regex_matches == ms)

@@ -28,7 +28,11 @@ def test_cpp_verify_email_and_panic(tmp_path):
     rc_, out = run(tmp_path, ok)
     fd = hashlib.sha256(ok.email.from_domain.encode()).hexdigest()
     pk = hashlib.sha256(ok.email.public_key.key).hexdigest()
-    assert rc_ == 0 and out == f"OK {fd} {pk}"
+    lines = out.splitlines()
+    assert rc_ == 0 and lines[0] == f"OK {fd} {pk}"
+    from zkemail_rs_amd import abi_encode as ae
+    from zkemail_rs_amd._abi import EmailVerifierOutput
+    assert lines[1] == "ABI " + ae.abi_encode(EmailVerifierOutput(bytes.fromhex(fd), bytes.fromhex(pk), [])).hex()
     rc_, out = run(tmp_path, cs["fail_body_flipped"])
     assert rc_ == 1 and out == "PANIC 4 11"          # circuits.rs:13, body hash did not verify
 
@@ -39,6 +43,11 @@ def test_cpp_verify_email_with_regex(tmp_path):
     (tmp_path / "f.dfa").write_bytes(d.fwd)
     (tmp_path / "b.dfa").write_bytes(d.bwd)
     rc_, out = run(tmp_path, ok, [str(tmp_path / "f.dfa"), str(tmp_path / "b.dfa"), "subject:"])
-    assert rc_ == 0 and out.startswith("OK ") and out.endswith("[subject:]")
+    lines = out.splitlines()
+    assert rc_ == 0 and lines[0].startswith("OK ") and lines[0].endswith("[subject:]")
+    from zkemail_rs_amd import abi_encode as ae
+    from zkemail_rs_amd._abi import EmailVerifierOutput
+    fd, pk = (bytes.fromhex(x) for x in lines[0].split()[1:3])
+    assert lines[1] == "ABI " + ae.abi_encode(EmailVerifierOutput(fd, pk, []), ["subject:"]).hex()
     rc_, out = run(tmp_path, ok, [str(tmp_path / "f.dfa"), str(tmp_path / "b.dfa"), "not-in-the-match"])
     assert rc_ == 1 and out == "PANIC 8 61"          # circuits.rs:45, capture not contained (regex.rs:44)

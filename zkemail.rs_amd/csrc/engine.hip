@@ -286,7 +286,57 @@ int set_stage_attr_any(zke_engine* e) {
 
 extern "C" {
 
-const char* zke_version(void) { return "zkemail.rs_amd 0.1 (gfx950)"; }
+const char* zke_version(void) { return "zkemail.rs_amd 0.2 (gfx950)"; }
+
+// ---- Solidity ABI encoding of the outputs (core/src/io.rs:5-53; alloy-sol-types' SolValue::abi_encode = abi.encode(value)).
+// The struct is a dynamic type: 32-byte offset 0x20, then the tuple's head / tail.  A string[] is its length, one offset
+// per element (relative to the start of the offsets), then each string as length + bytes padded to 32.
+namespace {
+struct AbiWriter {
+  uint8_t* out; size_t cap, len = 0;
+  void word(uint64_t v) { if (out && len + 32 <= cap) { memset(out + len, 0, 24); for (int i = 0; i < 8; i++) out[len + 24 + i] = (uint8_t)(v >> (56 - 8 * i)); } len += 32; }
+  void bytes(const uint8_t* p, size_t n) {
+    const size_t padded = (n + 31) & ~(size_t)31;
+    if (out && len + padded <= cap) { if (n) memcpy(out + len, p, n); memset(out + len + n, 0, padded - n); }
+    len += padded;
+  }
+};
+size_t abi_string_array_size(const size_t* lens, uint32_t n) {
+  size_t s = 32 + 32 * (size_t)n;
+  for (uint32_t i = 0; i < n; i++) s += 32 + ((lens[i] + 31) & ~(size_t)31);
+  return s;
+}
+void abi_string_array(AbiWriter& w, const uint8_t* const* strs, const size_t* lens, uint32_t n) {
+  w.word(n);
+  size_t off = 32 * (size_t)n;
+  for (uint32_t i = 0; i < n; i++) { w.word(off); off += 32 + ((lens[i] + 31) & ~(size_t)31); }
+  for (uint32_t i = 0; i < n; i++) { w.word(lens[i]); w.bytes(strs[i], lens[i]); }
+}
+}  // namespace
+
+int zke_abi_encode(const uint8_t* from_domain_hash, const uint8_t* public_key_hash, const uint8_t* const* external_inputs,
+                   const size_t* external_input_lens, uint32_t n_external_inputs, uint32_t with_matches,
+                   const uint8_t* const* matches, const size_t* match_lens, uint32_t n_matches, uint8_t* out, size_t out_cap,
+                   size_t* out_len) {
+  if (!from_domain_hash || !public_key_hash || !out_len || (n_external_inputs && (!external_inputs || !external_input_lens)) ||
+      (with_matches && n_matches && (!matches || !match_lens)) || (out_cap && !out))
+    return ZKE_E_ARG;
+  for (uint32_t i = 0; i < n_external_inputs; i++) if (external_input_lens[i] && !external_inputs[i]) return ZKE_E_ARG;
+  for (uint32_t i = 0; with_matches && i < n_matches; i++) if (match_lens[i] && !matches[i]) return ZKE_E_ARG;
+  const size_t email_tuple = 32 + 32 + 32 + abi_string_array_size(external_input_lens, n_external_inputs);
+  const size_t need = with_matches ? 32 + 64 + email_tuple + abi_string_array_size(match_lens, n_matches) : 32 + email_tuple;
+  *out_len = need;
+  if (need > out_cap) return out_cap == 0 && !out ? 0 : ZKE_E_NOMEM;
+  AbiWriter w{out, out_cap};
+  w.word(0x20);
+  if (with_matches) { w.word(0x40); w.word(0x40 + email_tuple); }
+  w.bytes(from_domain_hash, 32);
+  w.bytes(public_key_hash, 32);
+  w.word(0x60);
+  abi_string_array(w, external_inputs, external_input_lens, n_external_inputs);
+  if (with_matches) abi_string_array(w, matches, match_lens, n_matches);
+  return w.len == need ? 0 : ZKE_E_ARG;
+}
 
 int zke_device_available(void) {
   int n = 0;

@@ -81,6 +81,9 @@ def load_library(path: Optional[str] = None):
     lib.zke_rsa_modexp_batch.restype = C.c_int
     lib.zke_ed25519_verify_batch.argtypes = [vp, vp, vp, C.c_uint32, vp, C.c_uint32, vp]
     lib.zke_ed25519_verify_batch.restype = C.c_int
+    lib.zke_abi_encode.argtypes = [vp, vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.c_uint32, C.c_uint32, C.POINTER(vp), C.POINTER(C.c_size_t),
+                                   C.c_uint32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.zke_abi_encode.restype = C.c_int
     lib.zke_version.argtypes = []
     lib.zke_version.restype = C.c_char_p
     lib.zke_device_available.argtypes = []
@@ -95,6 +98,7 @@ EXPORTED_SYMBOLS = [
     "zke_verify_batch_device", "zke_engine_sync", "zke_get_timings", "zke_set_timing", "zke_verify_email",
     "zke_sha256_batch", "zke_sha256_batch_device", "zke_rsa_modexp_batch", "zke_version", "zke_device_available",
     "zke_ed25519_verify_batch", "zke_engine_reserve", "zke_get_slot_timings", "zke_verify_email_with_regex",
+    "zke_abi_encode",
 ]
 
 
@@ -316,3 +320,34 @@ def verify_email(email: Email) -> EmailVerifierOutput:
 
 def verify_email_with_regex(inp: EmailWithRegex) -> EmailWithRegexVerifierOutput:
     return default_engine().verify_email_with_regex(inp)
+
+
+def abi_encode_native(email: EmailVerifierOutput, matches: Optional[Sequence[str]] = None) -> bytes:
+    """VerificationOutput::from_parts(email, matches).abi_encode() (core/src/io.rs:28-44) through the C entry point
+    zke_abi_encode — what a zkVM host linking the C-ABI commits as public values.  (zkemail.rs_amd/abi_encode.py is the
+    same encoding in Python, with the decoder of helpers/src/io.rs.)"""
+    lib = load_library()
+
+    def table(strs):
+        bs = [s.encode("utf-8") if isinstance(s, str) else bytes(s) for s in strs]
+        bufs = [np.frombuffer(b or b"\0", np.uint8) for b in bs]
+        ptrs = (C.c_void_p * max(len(bs), 1))(*[x.ctypes.data for x in bufs])
+        lens = (C.c_size_t * max(len(bs), 1))(*[len(b) for b in bs])
+        return bufs, ptrs, lens, len(bs)
+
+    fd = np.frombuffer(bytes(email.from_domain_hash), np.uint8)
+    pk = np.frombuffer(bytes(email.public_key_hash), np.uint8)
+    if len(fd) != 32 or len(pk) != 32:                                    # io.rs:49-50 try_into().unwrap()
+        raise ValueError("hashes must be 32 bytes")
+    k1, p1, l1, n1 = table(email.external_inputs)
+    k2, p2, l2, n2 = table(matches or [])
+    need = C.c_size_t()
+    args = [fd.ctypes.data, pk.ctypes.data, p1, l1, n1, 0 if matches is None else 1, p2, l2, n2]
+    rc = lib.zke_abi_encode(*args, None, 0, C.byref(need))
+    if rc != 0:
+        raise EngineError(f"zke_abi_encode failed ({rc})")
+    out = np.zeros(need.value, np.uint8)
+    rc = lib.zke_abi_encode(*args, out.ctypes.data, need.value, C.byref(need))
+    if rc != 0:
+        raise EngineError(f"zke_abi_encode failed ({rc})")
+    return out.tobytes()
