@@ -98,6 +98,36 @@ def test_dfa_search_semantics_parity(engine, oracle):
                 assert (int(got[i]["match_start"]), int(got[i]["match_end"])) == spans[0], (pat, hay)
 
 
+def test_unicode_mode_dfas_parity(engine, oracle):
+    """DFAs compiled the way the reference compiles them (helpers/src/regex.rs:20: Unicode classes, UTF-8 automata,
+    flags.is_utf8 = 1 — some of them megabytes of table, walked from HBM instead of LDS) as BODY parts over non-ASCII
+    bodies: records equal to the oracle's, spans equal to the `regex` module's on the decoded text."""
+    pytest.importorskip("regex")
+    from test_regex_dfa import UNI_PATTERNS, UNI_HAYS, rust_find_iter_unicode
+    k0 = synth.load_keys()["rsa2048_00"]
+    hdrs = synth.std_headers(np.random.default_rng(1), 1, "example.com")
+    emails, texts = [], []
+    for text in UNI_HAYS:
+        if "\n" in text.replace("\r\n", ""):
+            continue                                     # a bare LF is not a line of an e-mail body
+        t = text if text.endswith("\r\n") else text + "\r\n"
+        raw, it = synth.sign_email(hdrs, t.encode("utf-8"), k0, synth.SignSpec(header_canon="simple", body_canon="simple"))
+        emails.append(A.Email("example.com", raw, A.PublicKey(k0.pkcs1_der)))
+        assert it["canon_body"] == t.encode("utf-8")
+        texts.append(t)
+    for pat in UNI_PATTERNS:
+        d = rc.create_dfa(pat, unicode=True)
+        ins = [A.EmailWithRegex(e, A.RegexInfo(None, [A.CompiledRegex(d, [])])) for e in emails]
+        got = engine.verify_batch(engine.pack_with_regex(ins))
+        exp = oracle.verify_batch(oracle.pack_with_regex(ins), threads=4)
+        assert_records_equal(got, exp, None, pat)
+        for i, t in enumerate(texts):
+            spans = rust_find_iter_unicode(pat, t)
+            assert int(got[i]["match_count"]) == min(len(spans), 2), (pat, t)
+            if spans:
+                assert (int(got[i]["match_start"]), int(got[i]["match_end"])) == spans[0], (pat, t)
+
+
 def test_long_haystacks_chunk_map_parity(engine, oracle):
     """dfa_wave_kernel cuts haystacks of 256+ bytes into 64 chunks and steps over the ones an idle-state walk
     passes unchanged: bodies of 300 B .. 9 KB with zero, one or two matches placed everywhere relative to the chunk

@@ -155,3 +155,101 @@ def test_compile_regex_parts_mirror():
         rc.compile_regex_parts([rc.RegexPattern(r"zzz", None)], inp)
     cfg = rc.RegexConfig.from_json({"header_parts": [{"pattern": "a", "capture_indices": [0]}], "body_parts": None})
     assert cfg.header_parts[0].capture_indices == [0] and cfg.body_parts is None
+
+
+# ---- Unicode mode: the reference compiles with regex-automata's defaults (helpers/src/regex.rs:20: Unicode classes,
+# UTF-8 automata, flags.is_utf8 = 1) — pinned against the `regex` module on the decoded haystack
+UNI_PATTERNS = [
+    r".", r".+", r"[^a]+", r"[^\r\n]+", r"\w+", r"\d+", r"\s+", r"\W+", r"\D", r"\S+", r"é+", r"[α-ω]+", r"[a-zà-ÿ]+", r"[^\x00-\x7f]+",
+    r"x*", r"", r"a?", r"from:[^\r\n]*<(\w+)@(\w+)\.com>", r"subject:.*\r\n", r"\w+@\w+", r"[\w.-]+", r"(?-u:[^a]+)", r"(?s:.+)",
+    r"(?s).+", r"日本|語", r"\x{1F600}", r"[\x{1F600}-\x{1F64F}]+", r"a.b", r"[^\W\d]+",
+]
+UNI_HAYS = ["", "abc", "café au lait", "αβγ δ", "日本語 text", "a😀b", "٣٤٥ 12", "x y z", "from:Ünï <ünï@exämple.com>\r\n",
+            "subject:héllo wörld\r\n", "a\nb", "éé é", "naïve façade", "̀combining", "𝔘𝔫𝔦 𝔠𝔬𝔡𝔢", "a.b aéb a\nb"]
+
+
+def rust_find_iter_unicode(pat: str, text: str):
+    """util::iter::Searcher over the `regex` module, spans in UTF-8 byte offsets; an empty match that abuts the last match
+    end advances by one code point (UTF-8 mode)."""
+    import regex
+    pat = re.sub(r"\\x\{([0-9A-Fa-f]+)\}", lambda m: chr(int(m.group(1), 16)), pat)       # the regex module spells it \U0001F600
+    rx = regex.compile(pat.replace("$", r"\Z"))
+    off = [0]
+    for ch in text:
+        off.append(off[-1] + len(ch.encode("utf-8")))
+    out, start, last_end = [], 0, None
+    while start <= len(text):
+        m = rx.search(text, start)
+        if m is None:
+            break
+        if m.start() == m.end() and last_end is not None and m.end() == last_end:
+            start += 1
+            if start > len(text):
+                break
+            m = rx.search(text, start)
+            if m is None:
+                break
+        out.append((off[m.start()], off[m.end()]))
+        start = m.end()
+        last_end = m.end()
+    return out
+
+
+@pytest.mark.parametrize("pat", UNI_PATTERNS)
+def test_unicode_mode_matches_the_regex_module(oracle, pat):
+    pytest.importorskip("regex")
+    d = rc.create_dfa(pat, unicode=True)
+    assert struct.unpack_from("<III", d.fwd, 44)[1] == 1          # flags.is_utf8
+    rid = oracle.dfa_register(d.fwd, d.bwd)
+    for text in UNI_HAYS:
+        hay = text.encode("utf-8")
+        n, spans = oracle.find_iter(rid, hay, 256)
+        assert n >= 0, (pat, text)
+        assert spans == rust_find_iter_unicode(pat, text), (pat, text)
+
+
+def test_unicode_classes_never_match_invalid_utf8(oracle):
+    """In Unicode mode a class ranges over scalar values: [^a] is "any code point but a", not "any byte but a" — stray
+    continuation bytes, overlong forms and surrogates end a match; (?-u:[^a]) is the byte class."""
+    def spans(pat, hay, **kw):
+        d = rc.create_dfa(pat, **kw)
+        return oracle.find_iter(oracle.dfa_register(d.fwd, d.bwd), hay, 64)[1]
+    assert spans(r"[^a]+", b"xy\xffz\xc3\xa9", unicode=True) == [(0, 2), (3, 6)]
+    assert spans(r"[^a]+", b"xy\xffz\xc3\xa9", unicode=False) == [(0, 6)]
+    assert spans(r"(?-u:[^a]+)", b"xy\xffz", unicode=True) == [(0, 4)]
+    assert spans(r".+", b"\xed\xa0\x80ok", unicode=True) == [(3, 5)]                  # U+D800 encoded: not a scalar value
+    assert spans(r".+", b"\xc0\xafok\xf4\x90\x80\x80", unicode=True) == [(2, 4)]      # overlong '/', and beyond U+10FFFF
+    assert spans(r"\w+", "naïve ٣x".encode(), unicode=True) == [(0, 6), (7, 10)]
+    assert spans(r"\w+", "naïve ٣x".encode(), unicode=False) == [(0, 2), (4, 6), (9, 10)]
+    assert spans(r"\d+", "٣٤x12".encode(), unicode=True) == [(0, 4), (5, 7)]
+    with pytest.raises(rc.RegexSyntaxError):
+        rc.create_dfa(r"\bfoo", unicode=True)                       # dense DFAs cannot hold a Unicode \b in the reference either
+
+
+def test_utf8_sequences_cover_exactly_the_range():
+    """The UTF-8 range splitting against Python's own encoder: every scalar value of a range is accepted by exactly one
+    sequence, nothing outside it is."""
+    rng = np.random.default_rng(8)
+    edges = [0, 0x7F, 0x80, 0x7FF, 0x800, 0xD7FF, 0xE000, 0xFFFF, 0x10000, 0x10FFFF]
+    for _ in range(60):
+        lo = int(rng.choice(edges)) + int(rng.integers(-3, 4)) if rng.random() < 0.5 else int(rng.integers(0, 0x110000))
+        hi = lo + int(rng.choice([0, 1, 63, 64, 2000, 70000, 0x10FFFF]))
+        lo, hi = min(max(0, lo), 0x10FFFF), min(0x10FFFF, hi)
+        seqs = rc._utf8_sequences(lo, hi)
+        def accepts(bs):
+            return sum(len(sq) == len(bs) and all(a <= b <= c for (a, c), b in zip(sq, bs)) for sq in seqs)
+        probe = {lo, hi, (lo + hi) // 2, max(lo - 1, 0), min(hi + 1, 0x10FFFF)} | {int(x) for x in rng.integers(0, 0x110000, 40)} | set(edges)
+        for cp in probe:
+            if 0xD800 <= cp <= 0xDFFF or cp > 0x10FFFF:
+                continue
+            assert accepts(chr(cp).encode("utf-8")) == (1 if lo <= cp <= hi else 0), (hex(lo), hex(hi), hex(cp))
+
+
+def test_compile_regex_parts_unicode_mirror():
+    """helpers/src/regex.rs:16-51 in its default (Unicode) mode on a non-ASCII input."""
+    inp = "from:Zoë <zoë@exämple.com>\r\nsubject:grüße\r\n".encode()
+    parts = rc.compile_regex_parts([rc.RegexPattern(r"from:[^\r\n]*<(\w+)@([\w.]+)>", [1, 2]), rc.RegexPattern(r"subject:(.*)\r\n", [1])], inp)
+    assert parts[0].captures == ["zoë", "exämple.com"] and parts[1].captures == ["grüße"]
+    assert struct.unpack_from("<III", parts[0].verify_re.fwd, 44)[1] == 1
+    bytes_mode = rc.compile_regex_parts([rc.RegexPattern(r"subject:([^\r\n]*)\r\n", [1])], inp, unicode=False)
+    assert bytes_mode[0].captures == ["grüße"] and struct.unpack_from("<III", bytes_mode[0].verify_re.fwd, 44)[1] == 0

@@ -5,12 +5,16 @@ leading padding stripped, :7-14) and ``compile_regex_parts`` (:16-51).  The refe
 with regex-automata's own compiler; no Rust toolchain exists here, so this is an independent
 compiler that emits the SAME WIRE FORMAT with the SAME SEARCH SEMANTICS (leftmost-first forward
 DFA with one-byte-delayed match states and an EOI transition; anchored, match-kind-all reverse
-DFA), not byte-identical tables.  It is byte-oriented: ``.`` is ``[^\\n]`` over bytes, classes
-are byte classes, no Unicode tables, no ``\\b``; flags.is_utf8 is 0 unless asked otherwise.
+DFA), not byte-identical tables.  Two modes: ``unicode=True`` is regex-automata's default syntax, the
+one the reference compiles with — ``.``, classes, ``\\d \\w \\s`` and negations range over Unicode scalar
+values and become UTF-8 byte-sequence automata, flags.is_utf8 = 1; ``unicode=False`` is ``(?-u)``
+throughout: bytes, flags.is_utf8 = 0.  No ``\\b`` (a dense DFA cannot hold a Unicode word boundary in
+the reference either), no case-insensitive flag.
 
 Supported syntax: literals, escapes (\\d \\w \\s \\D \\W \\S \\n \\r \\t \\f \\v \\0 \\xHH and escaped
 punctuation), ``.``, classes ``[a-z0-9_]`` / ``[^...]``, groups ``( )`` ``(?: )``, alternation,
-greedy and lazy ``* + ? {m} {m,} {m,n}``, ``^`` and ``$`` (text anchors, not multi-line).
+greedy and lazy ``* + ? {m} {m,} {m,n}``, ``^`` and ``$`` (text anchors, not multi-line), ``\\x{HHHH}``, non-ASCII
+literals and class members, the inline flags ``(?s) (?-s) (?u) (?-u)`` and their scoped forms.
 """
 from __future__ import annotations
 
@@ -41,20 +45,181 @@ class Node:
     greedy: bool = True
 
 
-_ESC_CLASS = {
-    "d": frozenset(range(0x30, 0x3A)),
-    "w": frozenset(list(range(0x30, 0x3A)) + list(range(0x41, 0x5B)) + list(range(0x61, 0x7B)) + [0x5F]),
-    "s": frozenset([0x20, 0x09, 0x0A, 0x0B, 0x0C, 0x0D]),
-}
 _ALL = frozenset(range(256))
 _ESC_CHAR = {"n": 0x0A, "r": 0x0D, "t": 0x09, "f": 0x0C, "v": 0x0B, "0": 0x00, "a": 0x07}
+MAXCP = 0x10FFFF
+Ranges = List[Tuple[int, int]]          # sorted, disjoint, inclusive ranges of bytes (byte mode) or code points (Unicode mode)
+
+_ASCII_CLASS: Dict[str, Ranges] = {
+    "d": [(0x30, 0x39)],
+    "w": [(0x30, 0x39), (0x41, 0x5A), (0x5F, 0x5F), (0x61, 0x7A)],
+    "s": [(0x09, 0x0D), (0x20, 0x20)],
+}
+# White_Space (PropList.txt) — what regex-syntax's Unicode \s is
+_UNI_SPACE: Ranges = [(0x09, 0x0D), (0x20, 0x20), (0x85, 0x85), (0xA0, 0xA0), (0x1680, 0x1680), (0x2000, 0x200A), (0x2028, 0x2029),
+                      (0x202F, 0x202F), (0x205F, 0x205F), (0x3000, 0x3000)]
+_UNI_CACHE: Dict[str, Ranges] = {}
+
+
+def _norm(r: Sequence[Tuple[int, int]]) -> Ranges:
+    out: Ranges = []
+    for lo, hi in sorted(r):
+        if out and lo <= out[-1][1] + 1:
+            out[-1] = (out[-1][0], max(out[-1][1], hi))
+        else:
+            out.append((lo, hi))
+    return out
+
+
+def _negate(r: Ranges, top: int) -> Ranges:
+    out, nxt = [], 0
+    for lo, hi in _norm(r):
+        if lo > nxt:
+            out.append((nxt, lo - 1))
+        nxt = hi + 1
+    if nxt <= top:
+        out.append((nxt, top))
+    return out
+
+
+def _unicode_class(name: str) -> Ranges:
+    """\\d = Nd, \\w = Alphabetic + M + Nd + Pc + Join_Control, \\s = White_Space (regex-syntax, Unicode mode; UTS #18 Annex C).
+    Tables come from the `regex` module's Unicode database when it is importable (one scan of the code space, cached),
+    else from `unicodedata` general categories (no Other_Alphabetic: a few hundred combining vowel signs short)."""
+    if name == "s":
+        return _UNI_SPACE
+    if name in _UNI_CACHE:
+        return _UNI_CACHE[name]
+    try:
+        import regex as _rx
+        rx = _rx.compile(r"\p{Nd}" if name == "d" else r"[\p{Alphabetic}\p{M}\p{Nd}\p{Pc}\p{Join_Control}]")
+        hit = lambda cp: rx.match(chr(cp)) is not None   # noqa: E731
+    except ImportError:
+        import unicodedata as _ud
+        cats = {"Nd"} if name == "d" else {"Lu", "Ll", "Lt", "Lm", "Lo", "Nl", "Mn", "Mc", "Me", "Nd", "Pc"}
+        hit = lambda cp: _ud.category(chr(cp)) in cats or (name == "w" and cp in (0x200C, 0x200D))   # noqa: E731
+    out: Ranges = []
+    start = None
+    for cp in range(MAXCP + 2):
+        ok = cp <= MAXCP and not (0xD800 <= cp <= 0xDFFF) and hit(cp)
+        if ok and start is None:
+            start = cp
+        elif not ok and start is not None:
+            out.append((start, cp - 1))
+            start = None
+    _UNI_CACHE[name] = out
+    return out
+
+
+def _utf8_sequences(lo: int, hi: int) -> List[List[Tuple[int, int]]]:
+    """The scalar-value range [lo, hi] as UTF-8 byte-range sequences (each sequence: one byte range per position), in
+    ascending order — the utf8-ranges construction regex-syntax uses (RFC 3629; surrogates are not scalar values)."""
+    out: List[List[Tuple[int, int]]] = []
+    stack = [(lo, hi)]
+    while stack:
+        lo, hi = stack.pop()
+        if lo > hi:
+            continue
+        if lo <= 0xDFFF and hi >= 0xD800:                    # cut the surrogate gap out
+            stack.append((0xE000, hi))
+            stack.append((lo, 0xD7FF))
+            continue
+        split = False
+        for mx in (0x7F, 0x7FF, 0xFFFF):                     # one encoded length per piece
+            if lo <= mx < hi:
+                stack.append((mx + 1, hi))
+                stack.append((lo, mx))
+                split = True
+                break
+        if split:
+            continue
+        if hi <= 0x7F:
+            out.append([(lo, hi)])
+            continue
+        for i in (1, 2, 3):                                   # continuation bytes must span their whole range
+            m = (1 << (6 * i)) - 1
+            if (lo & ~m) != (hi & ~m):
+                if (lo & m) != 0:
+                    stack.append(((lo | m) + 1, hi))
+                    stack.append((lo, lo | m))
+                    split = True
+                    break
+                if (hi & m) != m:
+                    stack.append((hi & ~m, hi))
+                    stack.append((lo, (hi & ~m) - 1))
+                    split = True
+                    break
+        if split:
+            continue
+        a, b = chr(lo).encode("utf-8"), chr(hi).encode("utf-8")
+        out.append(list(zip(a, b)))
+    return out
+
+
+def _bytes_node(lo: int, hi: int) -> Node:
+    return Node("lit", byteset=frozenset(range(lo, hi + 1)))
+
+
+def _seq_trie_node(seqs: List[List[Tuple[int, int]]]) -> Node:
+    """Alternation of byte-range sequences with common leading ranges shared (keeps the NFA, and so the subset construction,
+    small: a Unicode \\w is ~750 ranges)."""
+    groups: Dict[Tuple[int, int], List[List[Tuple[int, int]]]] = {}
+    order: List[Tuple[int, int]] = []
+    for sq in seqs:
+        if sq[0] not in groups:
+            groups[sq[0]] = []
+            order.append(sq[0])
+        groups[sq[0]].append(sq[1:])
+    alts = []
+    for first in order:
+        rests = [r for r in groups[first] if r]
+        head = _bytes_node(*first)
+        alts.append(head if not rests else Node("cat", kids=[head, _seq_trie_node(rests)]))
+    return alts[0] if len(alts) == 1 else Node("alt", kids=alts)
+
+
+def _class_node(r: Ranges, unicode: bool) -> Node:
+    """A character class as an AST over BYTES: byte mode = one byte set; Unicode mode = the UTF-8 encodings of its scalar values."""
+    r = _norm(r)
+    if not unicode:
+        return Node("lit", byteset=frozenset(b for lo, hi in r for b in range(lo, hi + 1)))
+    if not r:
+        return Node("lit", byteset=frozenset())               # matches nothing
+    if r[-1][1] <= 0x7F:
+        return Node("lit", byteset=frozenset(b for lo, hi in r for b in range(lo, hi + 1)))
+    seqs: List[List[Tuple[int, int]]] = []
+    ascii_bytes = set()
+    for lo, hi in r:
+        for sq in _utf8_sequences(lo, hi):
+            if len(sq) == 1:
+                ascii_bytes.update(range(sq[0][0], sq[0][1] + 1))
+            else:
+                seqs.append(sq)
+    kids = []
+    if ascii_bytes:
+        kids.append(Node("lit", byteset=frozenset(ascii_bytes)))
+    if seqs:
+        t = _seq_trie_node(seqs)
+        kids += t.kids if t.kind == "alt" else [t]
+    return kids[0] if len(kids) == 1 else Node("alt", kids=kids)
 
 
 class _Parser:
-    def __init__(self, pat: str):
+    """regex-syntax's surface, the part e-mail patterns use.  unicode=True (regex-automata's default, what
+    helpers/src/regex.rs:20 builds with): `.`, classes, \\d \\w \\s and their negations range over Unicode scalar values and
+    compile to UTF-8 byte sequences — a negated class never matches a stray byte >= 0x80.  unicode=False: bytes.
+    Inline flags: (?s) (?-s) (?u) (?-u) and the scoped forms (?s:...) (?-u:...)."""
+
+    def __init__(self, pat: str, unicode: bool = False):
         self.s = pat
         self.i = 0
         self.ngroups = 0
+        self.unicode = unicode
+        self.dotall = False
+
+    @property
+    def top(self) -> int:
+        return MAXCP if self.unicode else 0xFF
 
     def peek(self):
         return self.s[self.i] if self.i < len(self.s) else None
@@ -71,22 +236,28 @@ class _Parser:
         return n
 
     def alt(self) -> Node:
+        saved = (self.unicode, self.dotall)                   # (?flags) lasts to the end of the enclosing group
         branches = [self.cat()]
         while self.peek() == "|":
             self.eat()
             branches.append(self.cat())
+        self.unicode, self.dotall = saved
         return branches[0] if len(branches) == 1 else Node("alt", kids=branches)
 
     def cat(self) -> Node:
         items = []
         while self.peek() is not None and self.peek() not in "|)":
-            items.append(self.rep())
+            a = self.rep()
+            if a is not None:
+                items.append(a)
         if not items:
             return Node("empty")
         return items[0] if len(items) == 1 else Node("cat", kids=items)
 
-    def rep(self) -> Node:
+    def rep(self) -> Optional[Node]:
         a = self.atom()
+        if a is None:
+            return None
         while True:
             c = self.peek()
             if c == "*":
@@ -114,36 +285,78 @@ class _Parser:
             a = Node("rep", kids=[a], lo=lo, hi=hi, greedy=greedy)
         return a
 
-    def escape(self, in_class: bool):
+    def escape(self) -> Ranges:
         if self.peek() is None:
             raise RegexSyntaxError("dangling backslash")
         c = self.eat()
         if c in "dws":
-            return _ESC_CLASS[c]
+            return _unicode_class(c) if self.unicode else _ASCII_CLASS[c]
         if c in "DWS":
-            return _ALL - _ESC_CLASS[c.lower()]
+            return _negate(_unicode_class(c.lower()) if self.unicode else _ASCII_CLASS[c.lower()], self.top)
         if c == "x":
-            h = self.s[self.i:self.i + 2]
-            if len(h) != 2:
-                raise RegexSyntaxError("bad \\x escape")
-            self.i += 2
-            return frozenset([int(h, 16)])
+            if self.peek() == "{":
+                m = _pyre.match(r"\{([0-9a-fA-F]+)\}", self.s[self.i:])
+                if not m:
+                    raise RegexSyntaxError("bad \\x{...} escape")
+                self.i += m.end()
+                v = int(m.group(1), 16)
+            else:
+                h = self.s[self.i:self.i + 2]
+                if len(h) != 2:
+                    raise RegexSyntaxError("bad \\x escape")
+                self.i += 2
+                v = int(h, 16)
+            if v > self.top or (self.unicode and 0xD800 <= v <= 0xDFFF):
+                raise RegexSyntaxError("escape out of range")
+            if self.unicode is False and v > 0xFF:
+                raise RegexSyntaxError("escape out of range")
+            return [(v, v)]
         if c in _ESC_CHAR:
-            return frozenset([_ESC_CHAR[c]])
+            return [(_ESC_CHAR[c], _ESC_CHAR[c])]
+        if c in "bB":
+            # regex-automata cannot build a DFA with a Unicode word boundary either (dense::Builder errors), and the
+            # ASCII one, (?-u:\\b), needs look-behind state this compiler does not model
+            raise RegexSyntaxError("word boundaries are not supported")
         if c.isalnum():
             raise RegexSyntaxError(f"unsupported escape \\{c}")
-        return frozenset(c.encode("utf-8")) if len(c.encode("utf-8")) == 1 else None
+        return [(ord(c), ord(c))] if (self.unicode or ord(c) < 0x80) else None
 
-    def atom(self) -> Node:
+    def flags(self, text: str):
+        on = True
+        for ch in text:
+            if ch == "-":
+                on = False
+            elif ch == "u":
+                self.unicode = on
+            elif ch == "s":
+                self.dotall = on
+            else:
+                raise RegexSyntaxError(f"unsupported flag {ch!r}")
+
+    def literal(self, c: str) -> Node:
+        b = c.encode("utf-8")
+        if len(b) == 1:
+            return Node("lit", byteset=frozenset(b))
+        return Node("cat", kids=[Node("lit", byteset=frozenset([x])) for x in b])   # a non-ASCII literal is its UTF-8 bytes
+
+    def atom(self) -> Optional[Node]:
         c = self.eat()
         if c == "(":
-            if self.s.startswith("?:", self.i):
-                self.i += 2
-            elif self.peek() == "?":
-                raise RegexSyntaxError("unsupported group flag")
+            if self.peek() == "?":
+                m = _pyre.match(r"\?([a-z-]*)([:)])", self.s[self.i:])
+                if not m:
+                    raise RegexSyntaxError("unsupported group syntax")
+                self.i += m.end()
+                if m.group(2) == ")":                         # (?flags): applies to the rest of the enclosing group
+                    self.flags(m.group(1))
+                    return None
+                saved = (self.unicode, self.dotall)
+                self.flags(m.group(1))                        # (?flags:...) and (?:...)
+                n = self.alt()
+                self.unicode, self.dotall = saved
             else:
                 self.ngroups += 1
-            n = self.alt()
+                n = self.alt()
             if self.peek() != ")":
                 raise RegexSyntaxError("missing )")
             self.eat()
@@ -151,31 +364,33 @@ class _Parser:
         if c == "[":
             return self.cls()
         if c == ".":
-            return Node("lit", byteset=_ALL - {0x0A})
+            return _class_node([(0, self.top)] if self.dotall else _negate([(0x0A, 0x0A)], self.top), self.unicode)
         if c == "^":
             return Node("start")
         if c == "$":
             return Node("end")
         if c == "\\":
-            bs = self.escape(False)
-            if bs is None:
+            r = self.escape()
+            if r is None:
                 raise RegexSyntaxError("non-ASCII escape")
-            return Node("lit", byteset=bs)
+            return _class_node(r, self.unicode)
         if c in "*+?{":
             if c == "{":
                 return Node("lit", byteset=frozenset([0x7B]))
             raise RegexSyntaxError(f"nothing to repeat at {self.i - 1}")
-        b = c.encode("utf-8")
-        if len(b) == 1:
-            return Node("lit", byteset=frozenset(b))
-        return Node("cat", kids=[Node("lit", byteset=frozenset([x])) for x in b])   # a UTF-8 literal is its bytes
+        return self.literal(c)
 
     def cls(self) -> Node:
         neg = False
         if self.peek() == "^":
             self.eat(); neg = True
-        items: set = set()
+        items: Ranges = []
         first = True
+
+        def one(ch: str) -> int:
+            if not self.unicode and ord(ch) > 0x7F:
+                raise RegexSyntaxError("non-ASCII in a class of a byte-mode ((?-u)) pattern")
+            return ord(ch)
         while True:
             if self.peek() is None:
                 raise RegexSyntaxError("missing ]")
@@ -184,36 +399,30 @@ class _Parser:
                 break
             first = False
             if c == "\\":
-                bs = self.escape(True)
-                if bs is None:
+                lo_set = self.escape()
+                if lo_set is None:
                     raise RegexSyntaxError("non-ASCII in class")
-                lo_set = bs
             else:
-                b = c.encode("utf-8")
-                if len(b) != 1:
-                    raise RegexSyntaxError("non-ASCII in class (byte-oriented compiler)")
-                lo_set = frozenset(b)
-            if len(lo_set) == 1 and self.peek() == "-" and self.i + 1 < len(self.s) and self.s[self.i + 1] != "]":
+                lo_set = [(one(c), one(c))]
+            single = len(lo_set) == 1 and lo_set[0][0] == lo_set[0][1]
+            if single and self.peek() == "-" and self.i + 1 < len(self.s) and self.s[self.i + 1] != "]":
                 self.eat()
                 d = self.eat()
                 if d == "\\":
-                    hs = self.escape(True)
-                    if hs is None or len(hs) != 1:
+                    hs = self.escape()
+                    if hs is None or len(hs) != 1 or hs[0][0] != hs[0][1]:
                         raise RegexSyntaxError("bad range end")
-                    hi = next(iter(hs))
+                    hi = hs[0][0]
                 else:
-                    hb = d.encode("utf-8")
-                    if len(hb) != 1:
-                        raise RegexSyntaxError("non-ASCII in class")
-                    hi = hb[0]
-                lo = next(iter(lo_set))
+                    hi = one(d)
+                lo = lo_set[0][0]
                 if hi < lo:
                     raise RegexSyntaxError("reversed range")
-                items.update(range(lo, hi + 1))
+                items.append((lo, hi))
             else:
-                items.update(lo_set)
-        bs = frozenset(items)
-        return Node("lit", byteset=(_ALL - bs) if neg else bs)
+                items += lo_set
+        r = _norm(items)
+        return _class_node(_negate(r, self.top) if neg else r, self.unicode)
 
 
 def _reverse(n: Node) -> Node:
@@ -485,9 +694,13 @@ def _serialize(b: _Built, *, start_kind: int, has_empty: bool, is_utf8: bool, al
     return bytes(out)
 
 
-def create_dfa(pattern: str, *, is_utf8: bool = False) -> DFA:
-    """helpers/src/regex.rs:7-14 create_dfa: forward + reverse dense DFA blobs, padding stripped."""
-    ast = _Parser(pattern).parse()
+def create_dfa(pattern: str, *, is_utf8: Optional[bool] = None, unicode: bool = False) -> DFA:
+    """helpers/src/regex.rs:7-14 create_dfa: forward + reverse dense DFA blobs, padding stripped.
+    unicode=True is what the reference builds (dfa::regex::Regex::new: Unicode classes, UTF-8 automata, flags.is_utf8 = 1);
+    unicode=False is the byte-oriented mode ((?-u) throughout, flags.is_utf8 = 0 unless asked)."""
+    if is_utf8 is None:
+        is_utf8 = unicode
+    ast = _Parser(pattern, unicode=unicode).parse()
     has_empty = _can_match_empty(ast)
     anchored = _always_start_anchored(ast)
     # forward: leftmost-first, StartKind::Both
@@ -528,18 +741,40 @@ class RegexConfig:                     # helpers/src/structs.rs:9-13 (the regex_
         return RegexConfig(parts(obj.get("header_parts")), parts(obj.get("body_parts")))
 
 
-def compile_regex_parts(parts: Sequence[RegexPattern], inp: bytes) -> List[CompiledRegex]:
-    """helpers/src/regex.rs:16-51: one match exactly, capture strings by group index (lossy UTF-8)."""
+def compile_regex_parts(parts: Sequence[RegexPattern], inp: bytes, *, unicode: bool = True) -> List[CompiledRegex]:
+    """helpers/src/regex.rs:16-51: exactly one match of the pattern in the input, the capture groups named by
+    capture_indices as (lossy UTF-8) strings, the DFA pair of create_dfa.  unicode=True is the reference's
+    dfa::regex::Regex::new / meta::Regex::new (Unicode classes over UTF-8).  The match and the groups come from an
+    independent engine: the `regex` module on the decoded input (its \\d \\w \\s are Unicode there), or Python's `re` on
+    the bytes in byte mode."""
     out = []
     for part in parts:
-        rx = _pyre.compile(part.pattern.encode("utf-8"), _pyre.DOTALL if False else 0)
-        ms = list(rx.finditer(inp))
+        text = None
+        if unicode:
+            try:
+                text = inp.decode("utf-8")
+            except UnicodeDecodeError:
+                if any(ord(ch) > 0x7F for ch in part.pattern) or _pyre.search(r"\\[dwsDWS]|\[\^|\.", part.pattern):
+                    raise ValueError("the input is not UTF-8 and the pattern has Unicode-aware elements: no independent engine "
+                                     "here can give its capture groups") from None
+        if text is not None:
+            try:
+                import regex as _rx
+                rx = _rx.compile(part.pattern)
+            except ImportError:
+                rx = _pyre.compile(part.pattern)
+            ms = list(rx.finditer(text))
+            grp = lambda m, gi: m.group(gi)   # noqa: E731
+        else:
+            rx = _pyre.compile(part.pattern.encode("utf-8"))
+            ms = list(rx.finditer(inp))
+            grp = lambda m, gi: None if m.group(gi) is None else m.group(gi).decode("utf-8", errors="replace")   # noqa: E731
         if len(ms) != 1:
             raise ValueError(f"Input doesn't match regex pattern: {part!r}")
         caps: List[str] = []
         for gi in part.capture_indices or []:
             if gi > rx.groups or ms[0].group(gi) is None:
                 raise ValueError("Capture group not found")
-            caps.append(ms[0].group(gi).decode("utf-8", errors="replace"))
-        out.append(CompiledRegex(create_dfa(part.pattern), caps))
+            caps.append(grp(ms[0], gi))
+        out.append(CompiledRegex(create_dfa(part.pattern, unicode=unicode), caps))
     return out
