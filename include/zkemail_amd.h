@@ -91,7 +91,10 @@ enum {
   /* ZKE_UNSUPPORTED, continued */
   ZKE_D_U_SIG_TOO_LONG       = 63, /* FWS-stripped tag values of one DKIM-Signature exceed ZKE_MAX_TAGBUF bytes */
   ZKE_D_U_TOO_MANY_SIGS      = 64, /* more failing same-domain signatures than the engine's signature rounds */
-  ZKE_D_U_SIG_B_REPEATED     = 65  /* (no longer produced: both front ends remove every occurrence of the raw b= value, as the reference does) */
+  ZKE_D_U_SIG_B_REPEATED     = 65, /* (no longer produced: both front ends remove every occurrence of the raw b= value, as the reference does) */
+  ZKE_D_U_DOMAIN_FOLD        = 66  /* from_domain holds U+212A KELVIN SIGN, the one non-ASCII character whose to_lowercase() is ASCII ("k"):
+                                      cfdkim compares d= and from_domain lower-cased as Unicode strings; the engine folds ASCII only,
+                                      which is exact for every other domain (d= itself is ASCII whenever it gets that far) */
 };
 
 #define ZKE_MAX_HEADERS 256u   /* header fields per email the device parser tables hold */

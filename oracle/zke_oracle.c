@@ -1192,6 +1192,12 @@ static void verify_one(const zke_batch* in, uint32_t i, zke_result* out, zke_deb
     out->rsa_bits = (mod_len == 1 && mod[0] == 0) ? 0 : bits;
   }
 
+  /* cfdkim compares signing_domain.to_lowercase() with from_domain.to_lowercase() (Unicode).  d= is ASCII whenever a
+   * signature gets that far (non-ASCII DKIM-Signature values are reported above), so folding ASCII alone is exact unless
+   * from_domain holds a non-ASCII character whose lower case is ASCII: U+212A KELVIN SIGN -> "k" is the only one. */
+  for (size_t q = 0; q + 2 < dom_len; q++)
+    if (dom[q] == 0xE2 && dom[q + 1] == 0x84 && dom[q + 2] == 0xAA) { out->status = ZKE_UNSUPPORTED; out->detail = ZKE_D_U_DOMAIN_FOLD; return; }
+
   /* cfdkim::verify_email_with_key: email.rs:31-33 */
   taglist_t tl; tl.tagbuf = sc->tagbuf;
   canon_t cn; cn.preimage = sc->preimage; cn.cbody = sc->cbody;

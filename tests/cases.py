@@ -166,6 +166,14 @@ def build_cases() -> List[Case]:
     cs.append(mk("pass_identity", _hdrs(7), _body(100, 11), k0, SignSpec(identity="@mail.example.com", domain="example.com")))
     cs.append(mk("pass_extra_tags_unfolded", _hdrs(7), _body(100, 11), k0, SignSpec(extra_tags="t=1790000000; x=1790000100; q=dns/txt; ", fold_sig=False)))
     cs.append(mk("pass_domain_case", _hdrs(7), _body(100, 11), k0, SignSpec(domain="Example.COM"), from_domain="eXAMPLE.com"))
+    # non-ASCII from_domain: to_lowercase() is Unicode in the reference.  A non-ASCII domain never equals an (ASCII) d= ...
+    cs.append(mk("neutral_from_domain_non_ascii", _hdrs(7), _body(100, 11), k0, SignSpec(domain="example.com"), from_domain="exämple.com",
+                 status=A.ZKE_DKIM_NOT_PASS, detail=A.D_NEUTRAL, check_inter=False))
+    cs.append(mk("neutral_from_domain_upper_non_ascii", _hdrs(7), _body(100, 11), k0, SignSpec(domain="example.com"), from_domain="EXÄMPLE.COM",
+                 status=A.ZKE_DKIM_NOT_PASS, detail=A.D_NEUTRAL, check_inter=False))
+    # ... except through U+212A KELVIN SIGN, whose lower case is ASCII "k": reported as unsupported, never guessed
+    cs.append(mk("unsupported_from_domain_kelvin_sign", _hdrs(7), _body(100, 11), k0, SignSpec(domain="example.kom"), from_domain="example.\u212Aom",
+                 status=A.ZKE_UNSUPPORTED, detail=A.D_U_DOMAIN_FOLD, check_inter=False))
     cs.append(mk("pass_sig_header_lowercase_name", _hdrs(7), _body(100, 11), k0, SignSpec(sig_header_name=b"dkim-signature"), check_inter=False))
 
     # ---- failing

@@ -74,6 +74,7 @@ D_RE_QUIT = 62
 D_U_SIG_TOO_LONG = 63
 D_U_TOO_MANY_SIGS = 64
 D_U_SIG_B_REPEATED = 65
+D_U_DOMAIN_FOLD = 66
 
 KEY_RSA, KEY_ED25519, KEY_OTHER = 0, 1, 2
 F_HDR_RELAXED, F_BODY_RELAXED, F_HAS_LENGTH, F_SHA1, F_ED25519 = 1, 2, 4, 8, 16

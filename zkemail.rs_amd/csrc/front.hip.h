@@ -516,6 +516,8 @@ __global__ __launch_bounds__(64) void front_kernel(FrontArgs A) {
     }
     sha_job(2, dom, dom_len, R->from_domain_hash);                            // circuits.rs:16
     sha_job(3, key, key_len, R->public_key_hash);                             // circuits.rs:17
+    for (uint32_t o = 0; o + 2 < dom_len; o++)                                // U+212A KELVIN SIGN lower-cases to ASCII "k": see parse.hip.h
+      if (dom[o] == 0xE2 && dom[o + 1] == 0x84 && dom[o + 2] == 0xAA) { finish(ZKE_UNSUPPORTED, ZKE_D_U_DOMAIN_FOLD); return; }
   }
 
   if (A.debug_stop == 4) return;

@@ -864,6 +864,14 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
     // the two output witnesses (core/src/circuits.rs:16-17)
     sha_job(2, dom.base, dom.len, R->from_domain_hash);
     sha_job(3, key.base, key.len, R->public_key_hash);
+    {
+      // cfdkim compares d= and from_domain lower-cased as Unicode strings; d= is ASCII whenever a signature gets that far,
+      // so folding ASCII alone is exact unless from_domain holds U+212A KELVIN SIGN (to_lowercase() = "k", the one
+      // non-ASCII character with an ASCII lower case): reported, never guessed
+      bool kelvin = false;
+      for (uint32_t o = lane; o + 2 < dom.len; o += 64) kelvin = kelvin || (ldb(dom, o) == 0xE2 && ldb(dom, o + 1) == 0x84 && ldb(dom, o + 2) == 0xAA);
+      if (__ballot(kelvin)) { finish(ZKE_UNSUPPORTED, ZKE_D_U_DOMAIN_FOLD); return; }
+    }
   }
 
   if (A.debug_stop == 4) return;
@@ -1107,9 +1115,13 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
   if (A.fuse_canon) canon_body_wave(B, i, 0, cand_flags, body_off, raw.len - body_off, cand_len_tag, L.stage);   // parsing is over: the staged head is dead
 }
 
+#ifndef ZKE_PARSE_PRIO
+#define ZKE_PARSE_PRIO 0
+#endif
 __global__ __launch_bounds__(64, 6) void parse_kernel(ParseArgs A) {
   __shared__ ParseLds L;
   if (blockIdx.x >= A.b.n) return;
+  if (ZKE_PARSE_PRIO) __builtin_amdgcn_s_setprio(ZKE_PARSE_PRIO);
   parse_email(A, blockIdx.x, L);
 }
 
