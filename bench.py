@@ -5,16 +5,18 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A step = one pass of the hot path (verify_email: parse -> canonicalise -> SHA-256 -> RSA-2048 ->
-verdict) over one batch of BASELINE.json configs[1]: 1 024 synthetic DKIM-signed e-mails, 4 KB
+A step = one pass of the hot path (verify_email: parse -> canonicalise -> SHA-256 beside RSA-2048 ->
+verdict; three launches) over one batch of BASELINE.json configs[1]: 1 024 synthetic DKIM-signed e-mails, 4 KB
 canonical body, RSA-2048, DKIM only.  Inputs are resident in HBM before the timed region; every
 rank verifies its own batch (independent e-mails: weak scaling, no data-path collective) and the
 per-e-mail witnesses (status + the two output hashes, 72 B) of every step are all-gathered over RCCL at the end of the
 timed region when N > 1.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` (the SHA-256
-batch kernel, HIP-event timed on the launch stream) and `cpu_baseline` (the CPU oracle — a port,
-not the Rust reference — on this box's host cores).
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` (the hash / modexp launch —
+SHA-256 groups beside the RSA roles — HIP-event timed on its slot's stream, with S batches in flight as in the timed
+region; the figures of a batch alone and of the timed region as a whole beside it) and `cpu_baseline` (the CPU oracle —
+a port, not the Rust reference — on this box's host cores).  `python bench.py --gpus N` without a launcher starts its
+N ranks itself (torch.distributed.run, one process per GPU).
 """
 from __future__ import annotations
 
@@ -291,10 +293,14 @@ def main():
     eng.set_timing(False)
 
     emails_per_s = world * n * args.steps / dt
-    # SHA-256 launch: algorithmic bytes = every byte hashed once + 32 B per digest
+    # the hash / modexp launch: algorithmic bytes = every byte hashed once + 32 B per digest ...
     hashed = wl.body_bytes + sum(len(it["canon_header"]) for it in wl.inter) + \
         sum(len(e.from_domain.encode()) + len(e.public_key.key) for e in wl.emails)
-    sha_bytes = hashed + 32 * 4 * n
+    # ... and the launch's RSA roles read the signature and the modulus (k bytes each), the key's cached R^2 (k bytes) and
+    # leave 36 bytes (EM's shape verdict + digest) per e-mail: 3 k + 36 = 804 B at RSA-2048
+    k_rsa = cfg.get("rsa_bits", 0) // 8
+    rsa_bytes = n * (3 * k_rsa + 36) if k_rsa else 0
+    sha_bytes = hashed + 32 * 4 * n + rsa_bytes
     sha_s = kern_flight["sha_us"] * 1e-6
     # HBM traffic of that launch from the PMC counters (rocprofv3 --pmc passes, committed under profiles/)
     traffic, traffic_src = None, None
@@ -306,11 +312,12 @@ def main():
     gbps_of = (lambda us: round(sha_bytes / (us * 1e-6) / 1e9, 3) if us and us > 0 else None)
     step_s = dt / args.steps
     roof = {
-        "bound": "hbm", "kernel": "sha256_pair_kernel<128>" if (4 * ((n + 63) // 64)) <= 512 else "sha256_batch_kernel<128>",
+        "bound": "hbm", "kernel": "hash_modexp_kernel<128> (SHA-256 groups + RSA roles, one launch)" if (4 * ((n + 63) // 64)) <= 512 else "sha256_batch_kernel<128>",
         "mode": f"{S} batches in flight (the timed region's mode): average duration of one launch, HIP events on its slot's stream",
         "achieved": gbps_of(kern_flight["sha_us"]), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(sha_bytes / sha_s / 1e9 / HBM_PEAK_GBS, 5) if sha_s > 0 else None,
-        "traffic": traffic, "traffic_source": traffic_src, "bytes_per_launch": sha_bytes, "launch_us": round(kern_flight["sha_us"], 2),
+        "traffic": traffic, "traffic_source": traffic_src, "bytes_per_launch": sha_bytes, "hashed_bytes": hashed + 32 * 4 * n,
+        "rsa_operand_bytes": rsa_bytes, "launch_us": round(kern_flight["sha_us"], 2),
         # the same launch when its batch has the chip to itself, and the rate at which the timed region as a whole hashed
         "alone": {"launch_us": round(kern_alone["sha_us"], 2), "achieved": gbps_of(kern_alone["sha_us"]),
                   "frac": round(gbps_of(kern_alone["sha_us"]) / HBM_PEAK_GBS, 5)} if kern_alone else None,

@@ -1,5 +1,5 @@
-"""Summarise the HBM traffic of the workload's SHA-256 launch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE),
-as profiles/r01_c2_sha_pmc.json.  gfx950: FETCH_SIZE counts 32-byte... units of KB after the guide's correction (x2).
+"""Summarise the HBM traffic of the workload's hash / modexp launch (round 1: its SHA-256 launch) from two rocprofv3 --pmc
+passes (FETCH_SIZE, WRITE_SIZE), as profiles/rNN_c2_sha_pmc.json.  gfx950: FETCH_SIZE counts 32-byte... units of KB after the guide's correction (x2).
 
     rocprofv3 --pmc FETCH_SIZE -d gpurun_out/p_c2_fetch -o runc --output-format csv -- python bench.py --steps 10 --warmup 2 --no-cpu --no-saturated --streams 1
     rocprofv3 --pmc WRITE_SIZE -d gpurun_out/p_c2_write -o runc --output-format csv -- python bench.py --steps 10 --warmup 2 --no-cpu --no-saturated --streams 1
@@ -12,7 +12,8 @@ def median_counter(d, counter):
     vals, name = [], None
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if "zke::sha256_" in r["Kernel_Name"] and r["Counter_Name"] == counter and int(r["Grid_Size"]) <= 128 * 1024:
+            if ("zke::sha256_" in r["Kernel_Name"] or "zke::hash_modexp_kernel" in r["Kernel_Name"]) and r["Counter_Name"] == counter \
+                    and int(r["Grid_Size"]) <= 128 * 1024:
                 vals.append(float(r["Counter_Value"]))
                 name = r["Kernel_Name"]
     return statistics.median(vals), name, len(vals)

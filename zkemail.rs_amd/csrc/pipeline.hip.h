@@ -217,6 +217,15 @@ void collect_timings(zke_engine* e, Slot& w) {
   t.total_us = dt(0, w.timed_marks - 1);
 }
 
+// see zke_engine_reserve: 256 bytes of private memory per lane (the front end's spills are 116), never written to `sink`
+__global__ void slot_warm_kernel(uint32_t* sink) {
+  volatile uint32_t buf[64];
+  for (int i = 0; i < 64; i++) buf[i] = (uint32_t)i * 2654435761u + threadIdx.x;
+  uint32_t acc = 0;
+  for (int i = 0; i < 64; i++) acc += buf[(i * 7 + threadIdx.x) & 63];
+  if (acc == 0x12345678u && sink) *sink = acc;
+}
+
 // The slot's workspace is about to be overwritten by a batch on stream s: whatever ran in it before must be over.
 // Same stream: stream order is enough.  Another stream: wait for the event recorded behind the previous batch.
 int acquire_slot(zke_engine* e, Slot& w, hipStream_t s) {
@@ -417,6 +426,30 @@ int zke_engine_reserve(zke_engine* e, uint32_t max_n, uint64_t max_raw_total, ui
   if (max_n)
     for (Slot* w : e->slots)
       if (int r = ensure_workspace(e, *w, max_n, max_raw_total, max_regex_parts != 0, max_regex_parts, false)) return r;
+  // A stream's hardware queue and the queue's scratch memory (the front end spills a few registers) come into being
+  // with the first launch that needs them — milliseconds, and they would land in the first batch of every slot.
+  // One trivial launch per slot, with more scratch per lane than any kernel of the pipeline, pays for both here.
+  // Then one empty e-mail through the whole pipeline of every slot: kernel code, kernel arguments and the slot's workspace
+  // pages have all been touched once before the first real batch arrives.
+  if (int r = e->misc.ensure(1024)) return fail(e, r, "workspace allocation");
+  HIPCHK(e, hipMemset(e->misc.p, 0, 1024));
+  zke_batch wb{};
+  wb.n = 1;
+  uint8_t* z = e->misc.as<uint8_t>();            // 1 KB of zeros: CSR offsets {0, 0}, empty blobs, key type "rsa"
+  wb.raw_blob = z + 512; wb.raw_off = reinterpret_cast<const uint64_t*>(z);
+  wb.domain_blob = z + 512; wb.domain_off = reinterpret_cast<const uint64_t*>(z);
+  wb.key_blob = z + 512; wb.key_off = reinterpret_cast<const uint64_t*>(z);
+  wb.key_type = z + 512; wb.ext_null = nullptr;
+  const bool timing = e->timing;
+  e->timing = false;
+  for (Slot* w : e->slots) {
+    hipLaunchKernelGGL(slot_warm_kernel, dim3(1), dim3(64), 0, w->stream, (uint32_t*)nullptr);
+    if (max_n)
+      if (int r = run_device_pipeline(e, *w, &wb, 0, reinterpret_cast<zke_result*>(z + 768), w->stream, false)) { e->timing = timing; return r; }
+  }
+  e->timing = timing;
+  HIPCHK(e, hipGetLastError());
+  for (Slot* w : e->slots) HIPCHK(e, hipStreamSynchronize(w->stream));
   return 0;
 }
 
