@@ -220,9 +220,8 @@ def main():
         (xengines[i % S] if xengines else eng).verify_batch_device(cb, totals[0], totals[1], totals[2], base_ptr + (i % n_slices) * rec_bytes, st)
 
     def fence():
-        eng.sync()
-        for xe in (xengines or []):
-            xe.sync()
+        # torch.cuda.synchronize() is a device-wide wait: it covers the engine's slot streams too (eng.sync() would add
+        # one hipStreamSynchronize per slot to the timed region for nothing)
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -311,22 +310,30 @@ def main():
             break
     gbps_of = (lambda us: round(sha_bytes / (us * 1e-6) / 1e9, 3) if us and us > 0 else None)
     step_s = dt / args.steps
+    agg_gbs = round(sha_bytes / step_s / 1e9, 3)
     roof = {
         "bound": "hbm", "kernel": "hash_modexp_kernel<128> (SHA-256 groups + RSA roles, one launch)" if (4 * ((n + 63) // 64)) <= 512 else "sha256_batch_kernel<128>",
-        "mode": f"{S} batches in flight (the timed region's mode): average duration of one launch, HIP events on its slot's stream",
-        "achieved": gbps_of(kern_flight["sha_us"]), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(sha_bytes / sha_s / 1e9 / HBM_PEAK_GBS, 5) if sha_s > 0 else None,
+        # The timed region keeps S launches of this kernel in flight: the chip-level rate is one launch's bytes per
+        # ms_per_step (the wall time the timed region spends per launch).  The latency of a single launch, under that load
+        # and alone, is given beside it — bytes / launch_us of those is what ONE launch achieves, not the chip.
+        "mode": f"timed region: {S} batches in flight; achieved = bytes_per_launch / ms_per_step (one launch of this kernel per step, "
+                f"{S} of them overlapping)",
+        "achieved": agg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(agg_gbs / HBM_PEAK_GBS, 5),
         "traffic": traffic, "traffic_source": traffic_src, "bytes_per_launch": sha_bytes, "hashed_bytes": hashed + 32 * 4 * n,
-        "rsa_operand_bytes": rsa_bytes, "launch_us": round(kern_flight["sha_us"], 2),
-        # the same launch when its batch has the chip to itself, and the rate at which the timed region as a whole hashed
-        "alone": {"launch_us": round(kern_alone["sha_us"], 2), "achieved": gbps_of(kern_alone["sha_us"]),
-                  "frac": round(gbps_of(kern_alone["sha_us"]) / HBM_PEAK_GBS, 5)} if kern_alone else None,
-        "aggregate": {"bytes_per_step": sha_bytes, "ms_per_step": round(step_s * 1e3, 4),
-                      "achieved": round(sha_bytes / step_s / 1e9, 3), "frac": round(sha_bytes / step_s / 1e9 / HBM_PEAK_GBS, 5),
-                      "note": "hashed bytes of one step / ms_per_step of the timed region: S launches overlap"},
+        "rsa_operand_bytes": rsa_bytes, "ms_per_step": round(step_s * 1e3, 4),
+        "per_launch": {
+            "in_flight": {"launch_us": round(kern_flight["sha_us"], 2), "achieved": gbps_of(kern_flight["sha_us"]),
+                          "frac": round(gbps_of(kern_flight["sha_us"]) / HBM_PEAK_GBS, 5),
+                          "how": f"HIP events around the launch on its slot's stream with {S} batches in flight (includes the wait for "
+                                 "the chip behind the previous launch of the batch; rocprofv3's kernel-only average is in "
+                                 "profiles/r02_bench_c2_inflight_kernel_stats.csv)"},
+            "alone": {"launch_us": round(kern_alone["sha_us"], 2), "achieved": gbps_of(kern_alone["sha_us"]),
+                      "frac": round(gbps_of(kern_alone["sha_us"]) / HBM_PEAK_GBS, 5),
+                      "how": "one batch at a time (--alone-steps); rocprofv3: profiles/r02_bench_c2_streams1_kernel_stats.csv"} if kern_alone else None,
+        },
         "note": "SHA-256 on CDNA4 is integer-VALU bound: the compression alone sustains 1.82 TB/s on this chip "
                 "(profiles/r01_ubench_sha_alu.txt: ~1400 VALU per 64-byte block at ~3.9 cycles each), and a 1024-message launch is "
-                "bounded by the 65-block dependency chain of one message (split over two waves: schedule / rounds); see DESIGN.md §3",
+                "bounded by the dependency chain of one message (65 blocks) and of one RSA wave beside it; see DESIGN.md §3",
     }
 
     # ---- the same SHA-256 kernel with enough independent messages to fill the chip (kernel capability, not the

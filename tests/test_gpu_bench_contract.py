@@ -30,6 +30,12 @@ def test_bench_json_contract():
         assert k in rf, k
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
+    # the chip-level rate of the timed region (S launches overlap) and, labelled, what a single launch does in that mode and alone
+    assert abs(rf["achieved"] - rf["bytes_per_launch"] / (j["ms_per_step"] * 1e-3) / 1e9) < 0.02 * rf["achieved"]
+    pl = rf["per_launch"]
+    for mode in ("in_flight", "alone"):
+        assert abs(pl[mode]["achieved"] - rf["bytes_per_launch"] / (pl[mode]["launch_us"] * 1e-6) / 1e9) < 0.02 * pl[mode]["achieved"]
+    assert pl["alone"]["launch_us"] < pl["in_flight"]["launch_us"] and rf["traffic"] is None or rf["traffic"] >= rf["hashed_bytes"]
     cb = j["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
