@@ -132,7 +132,7 @@ __device__ __forceinline__ void canon_body_wave(const BatchDev& B, uint32_t i, u
         if (fill) {                                                 // bytes of an earlier, dirty group still in LDS
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
-          for (uint32_t bq = 16u * lane; bq + 16 <= fill; bq += 1024) *(uint4_store_unaligned*)(regB + o + bq) = *(const uint4*)(lds + bq);
+          for (uint32_t b0 = 0; b0 + 16 <= fill; b0 += 1024) { const uint32_t bq = b0 + 16u * lane; if (bq + 16 <= fill) *(uint4_store_unaligned*)(regB + o + bq) = *(const uint4*)(lds + bq); }
           const uint32_t tb = (fill & ~15u) + lane;
           if (lane < 16 && tb < fill) regB[o + tb] = lds[tb];
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -263,7 +263,7 @@ __device__ __forceinline__ void canon_body_wave(const BatchDev& B, uint32_t i, u
             __builtin_amdgcn_wave_barrier();
           }
         }
-        for (uint32_t bq = 16u * lane; bq + 16 <= fill; bq += 1024) *(uint4_store_unaligned*)(regB + o + bq) = *(const uint4*)(lds + bq);
+        for (uint32_t b0 = 0; b0 + 16 <= fill; b0 += 1024) { const uint32_t bq = b0 + 16u * lane; if (bq + 16 <= fill) *(uint4_store_unaligned*)(regB + o + bq) = *(const uint4*)(lds + bq); }
         {
           const uint32_t tb = (fill & ~15u) + lane;
           if (lane < 16 && tb < fill) regB[o + tb] = lds[tb];

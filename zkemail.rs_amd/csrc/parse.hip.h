@@ -216,7 +216,10 @@ template <class F>   // copy s[a,b) through a byte map
 __device__ __forceinline__ void emit_map(Out& out, const Str& s, uint32_t a, uint32_t b, F f) {
   if (b <= a) return;
   if (out.o + (b - a) > out.cap) { out.overflow = true; return; }
-  for (uint32_t l = a + lane_id(); l < b; l += 64) out.p[out.o + (l - a)] = (uint8_t)f(ldb(s, l));
+  for (uint32_t base = a; base < b; base += 64) {            // uniform trip count: the loop control stays on the scalar unit
+    const uint32_t l = base + (uint32_t)lane_id();
+    if (l < b) out.p[out.o + (l - a)] = (uint8_t)f(ldb(s, l));
+  }
   out.o += b - a;
 }
 
@@ -292,6 +295,10 @@ struct ParseLds {
 // Header span table: 64 entries in LDS (10 KB of LDS per wave would cap a CU at 16 front-end waves; 6.7 KB lets the
 // register budget decide: 24), the rest — e-mails with more than 64 header fields — in the e-mail's scratch slot.
 // The overflow is written and read back by the same wave: the reads go around L1 (agent-scope atomic loads).
+// A value every lane holds alike (loaded from LDS or memory at a wave-uniform address), as a scalar: branches on it are
+// then scalar branches, not exec-mask regions — the parser's control flow is wave-uniform, but the compiler can only see
+// that where the values come out of v_readfirstlane / v_readlane.
+__device__ __forceinline__ uint32_t uni(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
 struct HdrSpan { uint32_t ks, ke, vs, ve; };
 __device__ __forceinline__ void hdr_put(ParseLds& L, uint32_t* ovf, uint32_t x, uint32_t ks, uint32_t ke, uint32_t vs, uint32_t ve) {
   if (lane_id() != 0) return;
@@ -299,9 +306,9 @@ __device__ __forceinline__ void hdr_put(ParseLds& L, uint32_t* ovf, uint32_t x, 
   p[0] = ks; p[1] = ke; p[2] = vs; p[3] = ve;
 }
 __device__ __forceinline__ HdrSpan hdr_get(const ParseLds& L, const uint32_t* ovf, uint32_t x) {
-  if (x < HDR_LDS_ENTRIES) return HdrSpan{L.hdr[4 * x], L.hdr[4 * x + 1], L.hdr[4 * x + 2], L.hdr[4 * x + 3]};
+  if (x < HDR_LDS_ENTRIES) return HdrSpan{uni(L.hdr[4 * x]), uni(L.hdr[4 * x + 1]), uni(L.hdr[4 * x + 2]), uni(L.hdr[4 * x + 3])};
   const uint32_t* p = ovf + 4 * (x - HDR_LDS_ENTRIES);
-  auto ld = [](const uint32_t* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  auto ld = [](const uint32_t* q) { return uni(__hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); };
   return HdrSpan{ld(p), ld(p + 1), ld(p + 2), ld(p + 3)};
 }
 
@@ -319,10 +326,11 @@ __device__ __forceinline__ bool strip_to_lds(ParseLds& L, const Str& v, uint32_t
   }
   return true;
 }
+__device__ __forceinline__ uint32_t tagf(const ParseLds& L, int id, int k) { return uni(L.tag[id][k]); }    // k: 0 raw_s, 1 raw_e, 2 val_off, 3 val_len
 __device__ __forceinline__ bool tagval_eq(const ParseLds& L, int id, const char* lit, uint32_t n) {
-  if (L.tag[id][3] != n) return false;
+  if (tagf(L, id, 3) != n) return false;
   bool bad = false;
-  if ((uint32_t)lane_id() < n) bad = L.tagbuf[L.tag[id][2] + lane_id()] != (uint8_t)lit[lane_id()];
+  if ((uint32_t)lane_id() < n) bad = L.tagbuf[tagf(L, id, 2) + lane_id()] != (uint8_t)lit[lane_id()];
   return __ballot(bad) == 0;
 }
 
@@ -383,17 +391,17 @@ __device__ __forceinline__ uint32_t validate_sig(ParseLds& L, const Str& v, uint
   if ((present & req) != req) return ZKE_D_MISSING_TAG;
   if (!tagval_eq(L, TG_V, "1", 1)) return ZKE_D_INCOMPATIBLE_VERSION;
   if (present & (1u << TG_I)) {   // user.ends_with(signing_domain)
-    const uint32_t il = L.tag[TG_I][3], dl = L.tag[TG_D][3];
+    const uint32_t il = tagf(L, TG_I, 3), dl = tagf(L, TG_D, 3), io = tagf(L, TG_I, 2), dofs = tagf(L, TG_D, 2);
     if (il < dl) return ZKE_D_DOMAIN_MISMATCH;
     bool bad = false;
     for (uint32_t o = 0; o < dl; o += 64) {
       const uint32_t l = o + lane_id();
-      if (l < dl) bad |= L.tagbuf[L.tag[TG_I][2] + il - dl + l] != L.tagbuf[L.tag[TG_D][2] + l];
+      if (l < dl) bad |= L.tagbuf[io + il - dl + l] != L.tagbuf[dofs + l];
     }
     if (__ballot(bad)) return ZKE_D_DOMAIN_MISMATCH;
   }
   {   // h= must name "from" (split on ':', lower-cased)
-    const uint32_t ho = L.tag[TG_H][2], hl = L.tag[TG_H][3];
+    const uint32_t ho = tagf(L, TG_H, 2), hl = tagf(L, TG_H, 3);
     bool found = false;
     for (uint32_t o = 0; o < hl; o += 64) {
       const uint32_t l = o + lane_id();
@@ -412,14 +420,14 @@ __device__ __forceinline__ uint32_t validate_sig(ParseLds& L, const Str& v, uint
 
 // usize::from_str (optional '+', decimal digits, no overflow) on a stripped tag value
 __device__ __forceinline__ bool parse_usize_tag(const ParseLds& L, int id, uint64_t& out) {
-  const uint8_t* s = L.tagbuf + L.tag[id][2];
-  const uint32_t n = L.tag[id][3];
+  const uint8_t* s = L.tagbuf + tagf(L, id, 2);
+  const uint32_t n = tagf(L, id, 3);
   uint32_t i = 0;
-  if (n && s[0] == '+') i = 1;
+  if (n && uni(s[0]) == '+') i = 1;
   if (i >= n) return false;
   uint64_t v = 0;
   for (; i < n; i++) {
-    const uint32_t c = s[i];
+    const uint32_t c = uni(s[i]);
     if (c < '0' || c > '9') return false;
     const uint64_t d = c - '0';
     if (v > (0xFFFFFFFFFFFFFFFFull - d) / 10) return false;
@@ -691,12 +699,12 @@ __device__ __forceinline__ bool decode_sig(const ParseLds& L, uint32_t off, uint
   uint32_t pad = 0, total = 0;
   const bool shape_ok = (n % 4) == 0;
   if (shape_ok && n) {
-    pad = (s[n - 1] == '=') ? ((s[n - 2] == '=') ? 2u : 1u) : 0u;
+    pad = (uni(s[n - 1]) == '=') ? ((uni(s[n - 2]) == '=') ? 2u : 1u) : 0u;
     total = 3 * (n / 4) - pad;
   }
   {   // zero the part of the field the decoded bytes will not cover
     const uint32_t zend = (shape_ok && total <= 512) ? 512 - total : 512;
-    for (uint32_t o = lane_id(); o < zend; o += 64) J->sig[o] = 0;
+    for (uint32_t base = 0; base < zend; base += 64) { const uint32_t o = base + (uint32_t)lane_id(); if (o < zend) J->sig[o] = 0; }
   }
   if (!shape_ok) return false;
   if (n == 0) return true;
@@ -778,8 +786,11 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
     // block (split, tag lists, canonicalisation) then costs LDS latency instead of a dependent L2 round trip.
     const uint32_t want = raw.len < PARSE_STAGE_BYTES ? raw.len : PARSE_STAGE_BYTES;
     const uint32_t full = want & ~15u;
-    for (uint32_t o = lane * 16; o < full; o += 64 * 16) *(uint4*)(L.stage + o) = *(const uint4_unaligned*)(raw.base + o);
-    for (uint32_t o = full + lane; o < want; o += 64) L.stage[o] = raw.base[o];
+    for (uint32_t base = 0; base < full; base += 64 * 16) {
+      const uint32_t o = base + (uint32_t)lane * 16;
+      if (o < full) *(uint4*)(L.stage + o) = *(const uint4_unaligned*)(raw.base + o);
+    }
+    { const uint32_t o = full + (uint32_t)lane; if (o < want) L.stage[o] = raw.base[o]; }        // want - full < 16
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     raw.lds = L.stage; raw.lds_len = want;
@@ -869,7 +880,10 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
       // so folding ASCII alone is exact unless from_domain holds U+212A KELVIN SIGN (to_lowercase() = "k", the one
       // non-ASCII character with an ASCII lower case): reported, never guessed
       bool kelvin = false;
-      for (uint32_t o = lane; o + 2 < dom.len; o += 64) kelvin = kelvin || (ldb(dom, o) == 0xE2 && ldb(dom, o + 1) == 0x84 && ldb(dom, o + 2) == 0xAA);
+      for (uint32_t base = 0; base + 2 < dom.len; base += 64) {
+        const uint32_t o = base + (uint32_t)lane;
+        kelvin = kelvin || (o + 2 < dom.len && ldb(dom, o) == 0xE2 && ldb(dom, o + 1) == 0x84 && ldb(dom, o + 2) == 0xAA);
+      }
       if (__ballot(kelvin)) { finish(ZKE_UNSUPPORTED, ZKE_D_U_DOMAIN_FOLD); return; }
     }
   }
@@ -883,7 +897,12 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
   uint32_t first_sig_hdr = NONE;
   uint32_t cand_flags = 0;
   uint64_t cand_len_tag = 0;
+  // lane x: where header field x's name starts and how long it is (fields 0..63; later ones are looked up one by one)
+  uint32_t hks_lane = 0, hnl_lane = NONE;
+  if ((uint32_t)lane < nh && lane < (int)HDR_LDS_ENTRIES) { hks_lane = L.hdr[4 * lane]; hnl_lane = L.hdr[4 * lane + 1] - hks_lane; }
+  const uint64_t sig_len_mask = __ballot(hnl_lane == 14u);          // only a 14-byte name can be "DKIM-Signature"
   for (uint32_t hx = 0; hx < nh; hx++) {
+    if (hx < 64 && !((sig_len_mask >> hx) & 1)) continue;
     const HdrSpan hs = hdr_get(L, hdr_ovf, hx);
     const uint32_t ks = hs.ks, ke = hs.ke, vs = hs.vs, ve = hs.ve;
     if (!span_ieq(raw, ks, ke - ks, DKIM_NAME, 14)) continue;
@@ -916,12 +935,13 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
     }
     if (A.mode == 0) {
       // signing_domain.to_lowercase() == from_domain.to_lowercase()
-      bool same = L.tag[TG_D][3] == dom.len;
+      bool same = tagf(L, TG_D, 3) == dom.len;
       if (same) {
         bool bad = false;
+        const uint32_t dofs = tagf(L, TG_D, 2);
         for (uint32_t o = 0; o < dom.len; o += 64) {
           const uint32_t l = o + lane;
-          if (l < dom.len) bad |= lower(L.tagbuf[L.tag[TG_D][2] + l]) != lower(ldb(dom, l));
+          if (l < dom.len) bad |= lower(L.tagbuf[dofs + l]) != lower(ldb(dom, l));
         }
         same = __ballot(bad) == 0;
       }
@@ -964,17 +984,17 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
     have_cand = true; err_after = 0;
 
     // ---- the b= value: decode, and locate its raw span for removal from the preimage
-    const uint32_t b_rs = L.tag[TG_B][0], b_re = L.tag[TG_B][1];
+    const uint32_t b_rs = tagf(L, TG_B, 0), b_re = tagf(L, TG_B, 1);
     if (A.mode == 0) {
       uint32_t sig_len = 0;
-      const bool b64ok = decode_sig(L, L.tag[TG_B][2], L.tag[TG_B][3], J, sig_len);
+      const bool b64ok = decode_sig(L, tagf(L, TG_B, 2), tagf(L, TG_B, 3), J, sig_len);
+      const uint32_t bh_o = tagf(L, TG_BH, 2), bh_l = tagf(L, TG_BH, 3);
       if (lane == 0) {
         M->sig_b64_ok = b64ok ? 1u : 0u;
         J->sig_len = sig_len;
-        const uint32_t bl = L.tag[TG_BH][3];
-        M->bh_len = bl;
+        M->bh_len = bh_l;
       }
-      for (uint32_t o = lane; o < 48; o += 64) M->bh[o] = o < L.tag[TG_BH][3] ? L.tagbuf[L.tag[TG_BH][2] + o] : 0;
+      for (uint32_t o = lane; o < 48; o += 64) M->bh[o] = o < bh_l ? L.tagbuf[bh_o + o] : 0;
     }
     // String::replace removes EVERY occurrence of the raw b= value (leftmost first, non-overlapping).  Normally the
     // tag's own span is the only one and the header is read through a one-excision view; when the value occurs
@@ -1006,7 +1026,7 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
         while (pos < v.len) {
           const uint32_t q = next_occurrence(pos, NONE);
           const uint32_t end = (q == NONE) ? v.len : q;
-          for (uint32_t l = pos + lane; l < end; l += 64) tmp[tn + (l - pos)] = (uint8_t)ldb(v, l);
+          for (uint32_t base = pos; base < end; base += 64) { const uint32_t l = base + (uint32_t)lane; if (l < end) tmp[tn + (l - pos)] = (uint8_t)ldb(v, l); }
           tn += end - pos;
           if (q == NONE) break;
           pos = q + bl;
@@ -1022,49 +1042,59 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
     Out out{regA, 0, capA, false};
     const bool hrel = (flags & ZKE_F_HDR_RELAXED) != 0;
     {
-      const uint8_t* h = L.tagbuf + L.tag[TG_H][2];
-      const uint32_t hl = L.tag[TG_H][3];
-      uint32_t st = 0;
-      for (uint32_t e = 0; e <= hl; e++) {
-        if (e != hl && h[e] != ':') continue;
-        // bottom-up cursor per (lower-cased) name: the latest earlier entry of h= with the same name decides
-        uint32_t start = nh;
-        {
-          uint32_t st2 = 0;
-          // replay the selection for earlier identical names (names per signature are few)
-          uint32_t cur = nh;
-          for (uint32_t e2 = 0; e2 < st; e2++) {
-            if (h[e2] != ':' ) continue;
-            // entry [st2, e2)
-            bool same = (e2 - st2) == (e - st);
-            if (same) {
-              bool bad = false;
-              for (uint32_t o = lane; o < e - st; o += 64) bad |= lower(h[st2 + o]) != lower(h[st + o]);
-              same = __ballot(bad) == 0;
-            }
-            if (same) {
-              uint32_t found = NONE;
-              for (uint32_t x = cur; x-- > 0;) {
-                const HdrSpan h2 = hdr_get(L, hdr_ovf, x);
-                const uint32_t ks2 = h2.ks, ke2 = h2.ke;
-                if (span_ieq(raw, ks2, ke2 - ks2, h + st2, e2 - st2)) { found = x; break; }
-              }
-              cur = (found == NONE) ? 0 : found;
-            }
-            st2 = e2 + 1;
-          }
-          start = cur;
+      const uint8_t* h = L.tagbuf + tagf(L, TG_H, 2);
+      const uint32_t hl = tagf(L, TG_H, 3);
+      // h= is split at every ':' (FWS is already stripped; empty entries count).  The ':' after position `from`, 64 bytes
+      // of the value per step, instead of a scalar walk over its bytes.
+      auto colon_after = [&](uint32_t from) -> uint32_t {
+        for (uint32_t base = from & ~63u; base < hl; base += 64) {
+          const uint32_t l = base + (uint32_t)lane;
+          const uint64_t m = __ballot(l < hl && l >= from && h[l] == ':');
+          if (m) return base + (uint32_t)__builtin_ctzll(m);
         }
-        uint32_t found = NONE;
-        for (uint32_t x = start; x-- > 0;) {
+        return hl;
+      };
+      // the last header field in front of index `start` whose name is name[0, len) (case-insensitive), or NONE:
+      // cfdkim walks the header list bottom-up with a cursor per name.  Fields 0..63 are tested by name LENGTH first, all
+      // at once (lane x holds field x's), so only fields whose name has the right length are compared.
+      auto find_last = [&](const uint8_t* name, uint32_t len, uint32_t start) -> uint32_t {
+        for (uint32_t x = start; x-- > 64;) {
           const HdrSpan h2 = hdr_get(L, hdr_ovf, x);
-          const uint32_t ks2 = h2.ks, ke2 = h2.ke;
-          if (span_ieq(raw, ks2, ke2 - ks2, h + st, e - st)) { found = x; break; }
+          if (span_ieq(raw, h2.ks, h2.ke - h2.ks, name, len)) return x;
         }
+        uint64_t m = __ballot((uint32_t)lane < start && (uint32_t)lane < nh && hnl_lane == len);
+        while (m) {
+          const uint32_t x = 63u - (uint32_t)__builtin_clzll(m);
+          m &= ~(1ull << x);
+          if (span_ieq(raw, __builtin_amdgcn_readlane(hks_lane, x), len, name, len)) return x;
+        }
+        return NONE;
+      };
+      uint32_t st = 0;
+      for (;;) {
+        const uint32_t e = colon_after(st);                  // entry [st, e)
+        // bottom-up cursor per (lower-cased) name: replay the selection of the earlier entries of h= with the same name
+        uint32_t cur = nh;
+        for (uint32_t st2 = 0; st2 < st;) {
+          const uint32_t e2 = colon_after(st2);              // < st: position st - 1 holds a ':'
+          bool same = (e2 - st2) == (e - st);
+          if (same) {
+            bool bad = false;
+            for (uint32_t base = 0; base < e - st; base += 64) { const uint32_t o = base + (uint32_t)lane; if (o < e - st) bad |= lower(h[st2 + o]) != lower(h[st + o]); }
+            same = __ballot(bad) == 0;
+          }
+          if (same) {
+            const uint32_t found = find_last(h + st2, e2 - st2, cur);
+            cur = (found == NONE) ? 0 : found;
+          }
+          st2 = e2 + 1;
+        }
+        const uint32_t found = find_last(h + st, e - st, cur);
         if (found != NONE) {
           const HdrSpan sp = hdr_get(L, hdr_ovf, found);
           emit_header(out, substr(raw, sp.ks, sp.ke), substr(raw, sp.vs, sp.ve), hrel, true);
         }
+        if (e >= hl) break;
         st = e + 1;
       }
     }
