@@ -50,7 +50,7 @@ def parse_args():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-saturated", action="store_true",
                     help="skip the chip-filling SHA-256 micro-benchmark (profile runs: keeps the kernel stats to the workload's launches)")
-    ap.add_argument("--streams", type=int, default=20,
+    ap.add_argument("--streams", type=int, default=22,
                     help="submission slots of the engine = batches in flight per GPU: step i runs in slot i %% S (a stream and a "
                          "workspace each; one engine, one key cache); 1 = strictly serial steps")
     ap.add_argument("--alone-steps", type=int, default=8,
@@ -121,7 +121,8 @@ def main():
     # HIP multiplexes streams onto 4 hardware queues by default.  Every slot stream needs a queue of its own, and the
     # null stream and the runtime's own queues come out of the same pool: with exactly S queues two slots end up
     # sharing one (measured: 20 slots on 20 queues 18.8 M e-mails/s, on 24 queues 23.1 M; more queues than streams
-    # change nothing, but idle queues beyond ~32 cost: 40 mapped queues 11.9 M).  profiles/r02_hw_queues.txt
+    # change nothing, but idle queues beyond ~32 cost: 40 mapped queues 11.9 M).  22 slots on 26 queues is the measured
+    # optimum (20 / 21 / 22 / 24 slots: 26.1 / 26.8 / 27.4 / 21.7 M).  profiles/r02_hw_queues.txt
     os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, min(args.streams, 28) + 4)))
 
     import torch

@@ -219,10 +219,10 @@ void collect_timings(zke_engine* e, Slot& w) {
 
 // see zke_engine_reserve: 256 bytes of private memory per lane (the front end's spills are 116), never written to `sink`
 __global__ void slot_warm_kernel(uint32_t* sink) {
-  volatile uint32_t buf[64];
-  for (int i = 0; i < 64; i++) buf[i] = (uint32_t)i * 2654435761u + threadIdx.x;
+  volatile uint32_t buf[512];
+  for (int i = 0; i < 512; i++) buf[i] = (uint32_t)i * 2654435761u + threadIdx.x;
   uint32_t acc = 0;
-  for (int i = 0; i < 64; i++) acc += buf[(i * 7 + threadIdx.x) & 63];
+  for (int i = 0; i < 512; i++) acc += buf[(i * 7 + threadIdx.x) & 511];
   if (acc == 0x12345678u && sink) *sink = acc;
 }
 

@@ -101,7 +101,10 @@ __device__ __forceinline__ void later_rounds(const EdVerdictArgs& A, uint32_t e,
   }
 }
 
-__global__ __launch_bounds__(64) void ed_verdict_kernel(EdVerdictArgs A) {
+#ifndef ZKE_VERDICT_WAVES
+#define ZKE_VERDICT_WAVES 1      // waves per SIMD the verdict launch is compiled for (1: 256 VGPRs, no spills)
+#endif
+__global__ __launch_bounds__(64, ZKE_VERDICT_WAVES) void ed_verdict_kernel(EdVerdictArgs A) {
   __shared__ ParseLds L;
   const BatchDev& B = A.fin.b;
   const int lane = threadIdx.x & 63;
