@@ -13,7 +13,7 @@ timeout -k 10 400 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_dr
 python -c "
 import json
 for f in ('bench_line','bench_driver_line'):
-    j=json.load(open('$out/'+f+'.json')); print(f, j['value'], j['ms_per_step'], j['roofline']['achieved'], j['roofline']['alone'], j['roofline']['aggregate']['achieved'], j['cpu_baseline']['value'])"
+    j=json.load(open('$out/'+f+'.json')); print(f, j['value'], j['ms_per_step'], j['roofline']['achieved'], j['roofline']['per_launch']['alone'], j['cpu_baseline']['value'])"
 B="--no-cpu --no-saturated"
 rm -rf $out/p_inflight $out/p_alone $out/p_instr $out/p_fetch $out/p_write
 rocprofv3 --kernel-trace --stats -d $out/p_inflight -o run --output-format csv -- python bench.py $B --steps 2000 --warmup 100 --alone-steps 0 > $out/p_inflight.log 2>&1 || { tail -20 $out/p_inflight.log; exit 1; }
