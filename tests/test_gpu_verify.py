@@ -182,9 +182,9 @@ def test_mixed_key_types_one_batch(engine, oracle):
     assert len(set(int(s) for s in exp["status"])) >= 3        # the fuzz reaches several outcomes
 
 
-def test_lane_front_end_variant_parity(tmp_path):
-    """The one-e-mail-per-lane front end (csrc/front.hip.h, ZKE_LANE_PARSE=1) must produce the same records as
-    the oracle on the corpus and the fuzz set; run in a subprocess because the choice is made at engine creation."""
+def test_lane_dfa_kernel_variant_parity(tmp_path):
+    """The lane-per-e-mail DFA kernel (ZKE_DFA_WAVE=0; the default is the wave-per-e-mail one) must produce the same records
+    as the oracle; run in a subprocess because the choice is made at engine creation."""
     import os, subprocess, sys, textwrap
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = textwrap.dedent(f"""
@@ -194,22 +194,14 @@ def test_lane_front_end_variant_parity(tmp_path):
         import zkemail_rs_amd as z
         import synth
         eng, orc = z.Engine(), oracle_lib.load()
-        t.test_case_corpus_parity(eng, orc)
-        for seed in (99, 7):
-            t.test_mutation_fuzz_parity(eng, orc, seed)
-        t.test_header_folds_at_every_chunk_offset(eng, orc)
-        t.test_repeated_b_value_is_removed_everywhere(eng, orc)
-        t.test_workload_parity(eng, orc, dict(n=70, body_len=20000, rsa_bits=2048, seed=7, ragged=True, invalid_frac=0.2))
         tr.test_first_signature_canonicalisation_parity(eng, orc)
         tr.test_regex_workload_parity(eng, orc, dict(n=96, body_len=4096, rsa_bits=4096, n_keys=8, n_header_parts=2,
                                                     n_body_parts=2, qp_frac=0.05, fail_frac=0.3, seed=5))
         tr.test_long_haystacks_chunk_map_parity(eng, orc)
-        print("lane front end ok")
+        print("lane dfa ok")
     """)
-    # ... and the lane-per-e-mail DFA kernel (the default is the wave-per-e-mail one)
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ZKE_LANE_PARSE="1", ZKE_DFA_WAVE="0"), capture_output=True, text=True,
-                       timeout=600)
-    assert r.returncode == 0 and "lane front end ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ZKE_DFA_WAVE="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "lane dfa ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_rsa_quad_kernel_variant_parity():

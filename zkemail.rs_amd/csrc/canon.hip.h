@@ -298,7 +298,7 @@ __device__ __forceinline__ void canon_body_wave(const BatchDev& B, uint32_t i, u
   }
 }
 
-// stand-alone launch: the canonicalize_signed_email pass (mode 1) and the lane-per-e-mail front end
+// stand-alone launch: the canonicalize_signed_email pass (mode 1), and mode 0 under ZKE_NO_FUSE_CANON=1
 __global__ __launch_bounds__(64) void canon_body_kernel(CanonArgs A) {
   const BatchDev& B = A.b;
   const uint32_t i = blockIdx.x;

@@ -18,7 +18,6 @@
 #include "sha256.hip.h"
 #include "rsa.hip.h"
 #include "parse.hip.h"
-#include "front.hip.h"
 #include "regex.hip.h"
 #include "rsa_kernel.hip.h"
 #include "rsa_quad.hip.h"
@@ -76,9 +75,8 @@ struct Slot {
   int timed_marks = 0;
   bool timed_regex = false;
   DevBuf meta, rsa_jobs, sha_jobs, rsa_ok, em_dbg, scratch_off, scratch, clean, meta2, scratch2, parts;
-  DevBuf lanews;   // LaneWs[n]: per-e-mail header table / tag records / tag values of the lane-per-e-mail front end
   DevBuf pending;  // device counters: e-mails that need another signature round
-  DevBuf* all[13] = {&meta, &rsa_jobs, &sha_jobs, &rsa_ok, &em_dbg, &scratch_off, &scratch, &clean, &meta2, &scratch2, &parts, &lanews, &pending};
+  DevBuf* all[12] = {&meta, &rsa_jobs, &sha_jobs, &rsa_ok, &em_dbg, &scratch_off, &scratch, &clean, &meta2, &scratch2, &parts, &pending};
   // hipGraph replay of a batch's kernel sequence (ZKE_GRAPHS=1).  The graph holds this slot's workspace
   // pointers, so it is valid only while none of them has been reallocated: `generation` counts reallocations.
   hipGraphExec_t graph_exec = nullptr;
@@ -115,10 +113,8 @@ struct zke_engine {
                                     // handful of e-mails is still answered sooner by the short chain of one signature per wave
   uint32_t rsa_oct_min = 128;       // ... for the eight-lane form of moduli above 2048 bits (ZKE_RSA_OCT_MIN)
   int sha_pair = -1;                // two-wave SHA-256 kernel: -1 by launch size, 0 never, 1 always (ZKE_SHA_PAIR)
-  bool wave_parse = true;           // front end: one e-mail per wavefront (parse.hip.h); ZKE_LANE_PARSE=1 selects the
-                                    // one-e-mail-per-lane variant (front.hip.h), see DESIGN.md §3
   uint32_t debug_skip_rsa = 0;      // ZKE_DEBUG_SKIP_RSA: ablation experiments (results are then meaningless)
-  uint32_t fuse_canon = 1;          // body canonicalisation inside the wave-per-e-mail front end (ZKE_NO_FUSE_CANON=1: own launch)
+  uint32_t fuse_canon = 1;          // body canonicalisation inside the front end (ZKE_NO_FUSE_CANON=1: own launch)
   uint32_t debug_skip_ed = 0;       // ZKE_DEBUG_SKIP_ED: ablation, drops the Ed25519 stage launch (Ed25519 e-mails then fail)
   uint32_t debug_parse_stop = 0;    // ZKE_DEBUG_PARSE_STOP: timing experiments (results are then meaningless)
   uint32_t max_sig_rounds = 16;     // same-domain signatures tried per e-mail before ZKE_D_U_TOO_MANY_SIGS (options.reserved[0], up to 256)
@@ -373,7 +369,6 @@ int zke_engine_create(const zke_options* opt, zke_engine** out) {
   }
   if (opt && opt->reserved[0]) e->max_sig_rounds = std::min<uint32_t>(opt->reserved[0], ZKE_MAX_HEADERS);
   if (const char* g = getenv("ZKE_GRAPHS")) e->use_graphs = atoi(g) != 0;
-  if (getenv("ZKE_LANE_PARSE")) e->wave_parse = false;
   if (const char* st = getenv("ZKE_SHA_TILE")) e->sha_tile = atoi(st);
   if (const char* sp = getenv("ZKE_SHA_PAIR")) e->sha_pair = atoi(sp);
   if (const char* rq = getenv("ZKE_RSA_QUAD")) e->rsa_quad = atoi(rq);

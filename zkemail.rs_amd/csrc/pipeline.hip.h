@@ -5,8 +5,6 @@
 
 namespace {
 
-constexpr size_t FRONT_LDS_BYTES = (size_t)64 * FRONT_ROW;
-
 inline uint64_t host_scratch_off(const uint64_t* raw_off, uint32_t i) { return scratch_offset(raw_off[i] - raw_off[0], i); }
 
 struct StageTimer {
@@ -29,7 +27,6 @@ int ensure_workspace(zke_engine* e, Slot& w, uint32_t n, uint64_t raw_total, boo
     if ((r = w.pending.ensure(64))) return fail(e, r, "workspace allocation");
     HIPCHK(e, hipMemset(w.pending.p, 0, 64));
   }
-  if (!e->wave_parse && (r = w.lanews.ensure((size_t)n * sizeof(LaneWs)))) return fail(e, r, "workspace allocation");
   if (want_em && (r = w.em_dbg.ensure((size_t)n * 512))) return fail(e, r, "workspace allocation");
   if (with_regex) {
     if ((r = w.meta2.ensure((size_t)n * sizeof(EmailMeta))) || (r = w.scratch2.ensure(scratch_bytes)) ||
@@ -45,7 +42,6 @@ int ensure_workspace(zke_engine* e, Slot& w, uint32_t n, uint64_t raw_total, boo
 int set_kernel_attrs(zke_engine* e) {
   if (int r = set_sha_attrs_any(e)) return r;
   if (int r = set_stage_attr_any(e)) return r;
-  HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&front_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FRONT_LDS_BYTES));
   return 0;
 }
 int raise_dfa_lds_attrs(zke_engine* e, size_t lds) {
@@ -100,17 +96,12 @@ int run_device_pipeline(zke_engine* e, Slot& w, const zke_batch* in, uint64_t ra
   const uint32_t route_mask = rsa_route_mask(e, n, e->batch_key_total > (uint64_t)n * 272);
   {
     const uint32_t round = 0;
-    uint32_t* wave_count = e->wave_parse ? w.pending.as<uint32_t>() + 2 : nullptr;      // the lane-per-e-mail front end keeps no list
-    uint32_t* wave_list = e->wave_parse ? w.rsa_ok.as<uint32_t>() : nullptr;
-    if (e->wave_parse) {
-      ParseArgs pa{B, round, 0, e->debug_parse_stop, e->fuse_canon, e->key_cache.as<KeyCacheEntry>(), route_mask, wave_count, wave_list};
-      hipLaunchKernelGGL(parse_kernel, dim3(n), dim3(64), 0, s, pa);
-    } else {
-      FrontArgs fa{B, w.lanews.as<LaneWs>(), round, 0, e->debug_parse_stop};
-      hipLaunchKernelGGL(front_kernel, dim3((n + 63) / 64), dim3(64), FRONT_LDS_BYTES, s, fa);
-    }
+    uint32_t* wave_count = w.pending.as<uint32_t>() + 2;
+    uint32_t* wave_list = w.rsa_ok.as<uint32_t>();
+    ParseArgs pa{B, round, 0, e->debug_parse_stop, e->fuse_canon, e->key_cache.as<KeyCacheEntry>(), route_mask, wave_count, wave_list};
+    hipLaunchKernelGGL(parse_kernel, dim3(n), dim3(64), 0, s, pa);
     tm.mark();
-    if (!(e->wave_parse && e->fuse_canon)) {      // the wave-per-e-mail front end canonicalises the body itself
+    if (!e->fuse_canon) {      // the front end canonicalises the body itself
       CanonArgs ca{B, 0};
       hipLaunchKernelGGL(canon_body_kernel, dim3(n), dim3(64), 0, s, ca);
     }
@@ -135,13 +126,8 @@ int run_device_pipeline(zke_engine* e, Slot& w, const zke_batch* in, uint64_t ra
     B2.meta = w.meta2.as<EmailMeta>();
     B2.scratch = w.scratch2.as<uint8_t>();
     B2.meta_verify = B.meta;
-    if (e->wave_parse) {
-      ParseArgs pa{B2, 0, 1, 0, 0, nullptr, 0, nullptr, nullptr};
-      hipLaunchKernelGGL(parse_kernel, dim3(n), dim3(64), 0, s, pa);
-    } else {
-      FrontArgs fa{B2, w.lanews.as<LaneWs>(), 0, 1, 0};
-      hipLaunchKernelGGL(front_kernel, dim3((n + 63) / 64), dim3(64), FRONT_LDS_BYTES, s, fa);
-    }
+    ParseArgs pa{B2, 0, 1, 0, 0, nullptr, 0, nullptr, nullptr};
+    hipLaunchKernelGGL(parse_kernel, dim3(n), dim3(64), 0, s, pa);
     CanonArgs ca{B2, 1};
     hipLaunchKernelGGL(canon_body_kernel, dim3(n), dim3(64), 0, s, ca);
     QpArgs qa{B2, B.meta, w.clean.as<uint8_t>(), clean_off, B.scratch, B.scratch_off};
