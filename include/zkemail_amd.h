@@ -66,6 +66,8 @@ enum {
   ZKE_D_HDR_LEADING_SPACE    = 20, /* header line starts with ' ' */
   ZKE_D_HDR_LONE_CR          = 21, /* headers followed by a lone CR */
   ZKE_D_EMPTY_INPUT          = 22,
+  ZKE_D_SUBPART_LEADING_SPACE = 23, /* the same two errors in the header block of a MIME subpart (parse_mail walks the multipart tree) */
+  ZKE_D_SUBPART_LONE_CR      = 24,
   /* ZKE_KEY_DECODE_FAIL */
   ZKE_D_KEY_TYPE             = 30, /* key_type not "rsa"/"ed25519" */
   ZKE_D_KEY_DER              = 31, /* not a DER RSAPublicKey */
@@ -92,9 +94,12 @@ enum {
   ZKE_D_U_SIG_TOO_LONG       = 63, /* FWS-stripped tag values of one DKIM-Signature exceed ZKE_MAX_TAGBUF bytes */
   ZKE_D_U_TOO_MANY_SIGS      = 64, /* more failing same-domain signatures than the engine's signature rounds */
   ZKE_D_U_SIG_B_REPEATED     = 65, /* (no longer produced: both front ends remove every occurrence of the raw b= value, as the reference does) */
-  ZKE_D_U_DOMAIN_FOLD        = 66  /* from_domain holds U+212A KELVIN SIGN, the one non-ASCII character whose to_lowercase() is ASCII ("k"):
+  ZKE_D_U_DOMAIN_FOLD        = 66, /* from_domain holds U+212A KELVIN SIGN, the one non-ASCII character whose to_lowercase() is ASCII ("k"):
                                       cfdkim compares d= and from_domain lower-cased as Unicode strings; the engine folds ASCII only,
                                       which is exact for every other domain (d= itself is ASCII whenever it gets that far) */
+  ZKE_D_U_MIME_CTYPE         = 67, /* a Content-Type value that decides the subpart walk holds bytes >= 0x80 or an RFC 2047 encoded word */
+  ZKE_D_U_MIME_BOUNDARY      = 68, /* multipart boundary parameter folded across lines, or given only in an RFC 2231 form (boundary*, boundary*0) */
+  ZKE_D_U_MIME_DEPTH         = 69  /* multiparts nested more than 8 deep */
 };
 
 #define ZKE_MAX_HEADERS 256u   /* header fields per email the device parser tables hold */

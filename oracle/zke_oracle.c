@@ -411,54 +411,190 @@ int zko_rsa_pkcs1v15_sha256_verify(const uint8_t* mod, uint32_t k, uint64_t e, c
 }
 
 /* =================================================================== mailparse ==
- * mailparse 0.15.0 (Cargo.lock:1597) parse_headers / parse_header, call site
- * core/src/email.rs:26.  Only the top-level header list is restated; the MIME subpart
- * walk of parse_mail (whose only effect on this path is an extra Err on malformed
- * subpart headers) is not. */
+ * mailparse 0.15.0 (Cargo.lock:1597) parse_mail, call site core/src/email.rs:26: parse_headers / parse_header for the
+ * header list, then parse_mail_recursive's walk over the MIME subparts, whose only effect on this path is an Err (a panic
+ * at email.rs:26) when a subpart's header block is malformed.  Restated from recollection of the crate (its source is
+ * not in the container). */
+
+/* parse_header at raw[ix] (ix < len): spans of one header and the index after it; 0 or -ZKE_D_HDR_* */
+static int parse_one_header(const uint8_t* raw, size_t len, size_t ix, size_t* key_end, size_t* vs_out, size_t* ve_out, size_t* next) {
+  if (raw[ix] == ' ') return -(int)ZKE_D_HDR_LEADING_SPACE;
+  size_t p = ix, vs, ve;
+  while (p < len && raw[p] != ':' && raw[p] != '\n') p++;
+  if (p >= len) {             /* ran off the end inside the key: key = rest, empty value */
+    *key_end = len; vs = ve = len; p = len;
+  } else if (raw[p] == '\n') { /* key line without colon */
+    *key_end = p; vs = ve = p; p = p + 1;
+  } else {
+    *key_end = p;
+    p++;
+    while (p < len && raw[p] == ' ') p++;
+    vs = ve = p;
+    /* Value / ValueNewline states */
+    for (;;) {
+      if (p >= len) break;
+      uint8_t c = raw[p];
+      if (c == '\n') {
+        if (p + 1 < len && (raw[p + 1] == ' ' || raw[p + 1] == '\t')) { p++; continue; }
+        p++;
+        break;
+      }
+      if (c != '\r') ve = p + 1;
+      p++;
+    }
+    if (vs > len) vs = ve = len;
+  }
+  *vs_out = vs; *ve_out = ve; *next = p;
+  return 0;
+}
+/* parse_headers: 0 = a header starts at ix, 1 = the list ends (ix moved past the empty line), <0 = error */
+static int header_list_step(const uint8_t* raw, size_t len, size_t* ix) {
+  if (*ix >= len) return 1;
+  if (raw[*ix] == '\n') { *ix += 1; return 1; }
+  if (raw[*ix] == '\r') {
+    if (*ix + 1 < len && raw[*ix + 1] == '\n') { *ix += 2; return 1; }
+    return -(int)ZKE_D_HDR_LONE_CR;
+  }
+  return 0;
+}
 long zko_parse_headers(const uint8_t* raw, size_t len, uint32_t* spans, size_t max_headers, size_t* body_ix) {
   size_t ix = 0, nh = 0;
   for (;;) {
-    if (ix >= len) break;
-    if (raw[ix] == '\n') { ix += 1; break; }
-    if (raw[ix] == '\r') {
-      if (ix + 1 < len && raw[ix + 1] == '\n') { ix += 2; break; }
-      return -ZKE_D_HDR_LONE_CR;
-    }
-    /* parse_header state machine */
-    if (raw[ix] == ' ') return -ZKE_D_HDR_LEADING_SPACE;
-    size_t p = ix, key_end, vs, ve;
-    while (p < len && raw[p] != ':' && raw[p] != '\n') p++;
-    if (p >= len) {             /* ran off the end inside the key: key = rest, empty value */
-      key_end = len; vs = ve = len; p = len;
-    } else if (raw[p] == '\n') { /* key line without colon */
-      key_end = p; vs = ve = p; p = p + 1;
-    } else {
-      key_end = p;
-      p++;
-      while (p < len && raw[p] == ' ') p++;
-      vs = ve = p;
-      /* Value / ValueNewline states */
-      for (;;) {
-        if (p >= len) break;
-        uint8_t c = raw[p];
-        if (c == '\n') {
-          if (p + 1 < len && (raw[p + 1] == ' ' || raw[p + 1] == '\t')) { p++; continue; }
-          p++;
-          break;
-        }
-        if (c != '\r') ve = p + 1;
-        p++;
-      }
-      if (vs > len) vs = ve = len;
-    }
-    if (nh >= max_headers) return -ZKE_D_U_TOO_MANY_HEADERS;
+    int st = header_list_step(raw, len, &ix);
+    if (st < 0) return st;
+    if (st) break;
+    size_t key_end, vs, ve, next;
+    int r = parse_one_header(raw, len, ix, &key_end, &vs, &ve, &next);
+    if (r) return r;
+    if (nh >= max_headers) return -(long)ZKE_D_U_TOO_MANY_HEADERS;
     spans[4 * nh] = (uint32_t)ix; spans[4 * nh + 1] = (uint32_t)key_end;
     spans[4 * nh + 2] = (uint32_t)vs; spans[4 * nh + 3] = (uint32_t)ve;
     nh++;
-    ix = p;
+    ix = next;
   }
   if (body_ix) *body_ix = ix;
   return (long)nh;
+}
+
+/* ---- parse_mail_recursive: the subpart walk.
+ *   (headers, ix_body) = parse_headers(part)?                       an Err here is the panic of email.rs:26
+ *   ctype = parse_content_type(headers.get_first_value("Content-Type"))
+ *   if ctype.mimetype.starts_with("multipart/") && ctype.params has "boundary" && part.len() > ix_body:
+ *       boundary = "--" + params["boundary"]
+ *       the body ends at the first line that starts with the boundary; after each such line the next part runs from the
+ *       byte after the next LF to the next line that starts with the boundary (no such line: the rest is not a part);
+ *       each part is parsed recursively; "--" right after a boundary ends the walk.
+ * get_first_value: the first header whose key is "Content-Type" (eq_ignore_ascii_case); get_value() unfolds the raw
+ * value (lines(), each trim_start()ed, joined with one SP) and decodes RFC 2047 words; parse_param_content splits at
+ * every ';' (quotes do not protect one), trims, lower-cases the first token (the mimetype) and the parameter names,
+ * strips one pair of double quotes from a value, last duplicate wins; RFC 2231 forms (boundary*, boundary*0 ...) only
+ * matter when no plain "boundary" exists.
+ * The engine decides on the raw bytes, which is exact for ASCII values without encoded words and with the boundary on
+ * one line; what is not — bytes >= 0x80 or "=?" in a value that decides (str::trim() and to_lowercase() are Unicode-aware,
+ * decoded words can hold anything), a folded boundary value, RFC 2231 boundary forms, nesting beyond 8 multiparts — is
+ * ZKE_UNSUPPORTED, never a guess. */
+#define MIME_MAX_DEPTH 8
+static int rust_ws(uint8_t c) { return c == ' ' || (c >= 9 && c <= 13); }      /* ASCII members of White_Space */
+static void trim_span(const uint8_t* v, size_t* s, size_t* e) {
+  while (*s < *e && rust_ws(v[*s])) (*s)++;
+  while (*e > *s && rust_ws(v[*e - 1])) (*e)--;
+}
+static int ieq_lit(const uint8_t* v, size_t n, const char* lit) {
+  for (size_t i = 0; i < n; i++) {
+    uint8_t c = v[i];
+    if (c >= 'A' && c <= 'Z') c = (uint8_t)(c + 32);
+    if (c != (uint8_t)lit[i]) return 0;
+  }
+  return 1;
+}
+static int undecidable(const uint8_t* v, size_t s, size_t e, size_t n) {    /* v[s,e) holds a byte >= 0x80 or "=?" */
+  for (size_t i = s; i < e; i++)
+    if (v[i] >= 0x80 || (v[i] == '=' && i + 1 < n && v[i + 1] == '?')) return 1;
+  return 0;
+}
+/* 0: not a multipart with a boundary; 1: boundary value = v[*bs, *be); < 0: -ZKE_D_U_MIME_* */
+static int mime_content_type(const uint8_t* v, size_t n, size_t* bs, size_t* be) {
+  size_t t0e = 0;
+  while (t0e < n && v[t0e] != ';') t0e++;
+  if (undecidable(v, 0, t0e, n)) return -(int)ZKE_D_U_MIME_CTYPE;
+  size_t s = 0, e = t0e;
+  trim_span(v, &s, &e);
+  if (e - s < 10 || !ieq_lit(v + s, 10, "multipart/")) return 0;
+  if (undecidable(v, 0, n, n)) return -(int)ZKE_D_U_MIME_CTYPE;
+  int have = 0, starred = 0;
+  for (size_t p = t0e + 1; p <= n;) {
+    size_t q = p;
+    while (q < n && v[q] != ';') q++;
+    size_t eq = p;
+    while (eq < q && v[eq] != '=') eq++;
+    if (eq < q) {
+      size_t ks = p, ke = eq, vs = eq + 1, ve = q;
+      trim_span(v, &ks, &ke);
+      trim_span(v, &vs, &ve);
+      if (ve - vs > 1 && v[vs] == '"' && v[ve - 1] == '"') { vs++; ve--; }
+      if (ke - ks == 8 && ieq_lit(v + ks, 8, "boundary")) { have = 1; *bs = vs; *be = ve; }
+      else if (ke - ks >= 9 && ieq_lit(v + ks, 9, "boundary*")) starred = 1;
+    }
+    if (q >= n) break;
+    p = q + 1;
+  }
+  if (have) {
+    for (size_t i = *bs; i < *be; i++) if (v[i] == '\n') return -(int)ZKE_D_U_MIME_BOUNDARY;
+    return 1;
+  }
+  return starred ? -(int)ZKE_D_U_MIME_BOUNDARY : 0;
+}
+/* find_from_u8_line_prefix within raw[a, b): first pos >= from where "--" + raw[bs, be) starts a line */
+static size_t find_boundary_line(const uint8_t* raw, size_t a, size_t b, size_t from, size_t bs, size_t be) {
+  const size_t L = 2 + (be - bs);
+  for (size_t pos = from; pos + L <= b; pos++)
+    if ((pos == a || raw[pos - 1] == '\n') && raw[pos] == '-' && raw[pos + 1] == '-' && memcmp(raw + pos + 2, raw + bs, L - 2) == 0) return pos;
+  return (size_t)-1;
+}
+/* parse_mail_recursive over raw[a, b).  0, or ZKE_PARSE_FAIL / ZKE_UNSUPPORTED with *detail */
+static uint32_t mime_walk(const uint8_t* raw, size_t a, size_t b, int depth, uint32_t* detail) {
+  size_t ix = a, ct_s = 0, ct_e = 0;
+  int has_ct = 0;
+  for (;;) {
+    int st = header_list_step(raw, b, &ix);
+    if (st < 0) { *detail = depth ? ZKE_D_SUBPART_LONE_CR : (uint32_t)-st; return ZKE_PARSE_FAIL; }
+    if (st) break;
+    size_t key_end, vs, ve, next;
+    int r = parse_one_header(raw, b, ix, &key_end, &vs, &ve, &next);
+    if (r) { *detail = depth ? ZKE_D_SUBPART_LEADING_SPACE : (uint32_t)-r; return ZKE_PARSE_FAIL; }
+    if (!has_ct && key_end - ix == 12 && ieq_lit(raw + ix, 12, "content-type")) { has_ct = 1; ct_s = vs; ct_e = ve; }
+    ix = next;
+  }
+  if (!has_ct) return 0;
+  size_t bs = 0, be = 0;
+  int m = mime_content_type(raw + ct_s, ct_e - ct_s, &bs, &be);
+  if (m < 0) { *detail = (uint32_t)-m; return ZKE_UNSUPPORTED; }
+  if (m == 0 || !(b > ix)) return 0;
+  if (depth >= MIME_MAX_DEPTH) { *detail = ZKE_D_U_MIME_DEPTH; return ZKE_UNSUPPORTED; }
+  bs += ct_s; be += ct_s;
+  const size_t L = 2 + (be - bs);
+  size_t pos = find_boundary_line(raw, a, b, ix, bs, be);
+  if (pos == (size_t)-1) return 0;
+  size_t bend = pos + L;
+  for (;;) {
+    size_t nl = bend;
+    while (nl < b && raw[nl] != '\n') nl++;
+    if (nl >= b) break;
+    const size_t ps = nl + 1;
+    const size_t pe = find_boundary_line(raw, a, b, ps, bs, be);
+    if (pe == (size_t)-1) break;
+    uint32_t r = mime_walk(raw, ps, pe, depth + 1, detail);
+    if (r) return r;
+    bend = pe + L;
+    if (bend + 1 < b && raw[bend] == '-' && raw[bend + 1] == '-') break;
+  }
+  return 0;
+}
+uint32_t zko_mime_walk(const uint8_t* raw, size_t len, uint32_t* detail) {
+  uint32_t d = 0;
+  uint32_t r = mime_walk(raw, 0, len, 0, &d);
+  if (detail) *detail = d;
+  return r;
 }
 
 /* ====================================================================== cfdkim ==
@@ -1174,6 +1310,11 @@ static void verify_one(const zke_batch* in, uint32_t i, zke_result* out, zke_deb
   out->n_headers = (uint32_t)pm.nh;
   find_body(&pm);
   out->body_offset = (uint32_t)pm.body_off;
+  {
+    uint32_t md = 0;
+    const uint32_t mr = mime_walk(raw, 0, raw_len, 0, &md);      /* still email.rs:26: the subparts */
+    if (mr) { out->status = mr; out->detail = md; return; }
+  }
 
   uint8_t mod[ZKE_MAX_RSA_BYTES + 8]; uint32_t mod_len = 0; uint64_t e = 0;      /* email.rs:28-29 */
   const int ed_key = in->key_type[i] == ZKE_KEY_ED25519;

@@ -49,6 +49,8 @@ long zko_b64_decode(const uint8_t* in, size_t n, uint8_t* out);
  * as 4 uint32 per header; returns header count or -ZKE_D_* on the errors parse_mail raises */
 long zko_parse_headers(const uint8_t* raw, size_t len, uint32_t* spans, size_t max_headers,
                        size_t* body_ix);
+/* mailparse 0.15.0 parse_mail_recursive (the MIME subpart walk): 0, or ZKE_PARSE_FAIL / ZKE_UNSUPPORTED with *detail */
+uint32_t zko_mime_walk(const uint8_t* raw, size_t len, uint32_t* detail);
 
 /* cfdkim canonicalisation (RFC 6376 §3.4).  Output buffers must hold len+4 bytes. */
 size_t zko_canon_body(const uint8_t* body, size_t len, int relaxed, uint8_t* out);

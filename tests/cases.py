@@ -13,6 +13,7 @@ from typing import List, Optional
 import numpy as np
 
 from zkemail_rs_amd import _abi as A
+import mime_fuzz
 import synth
 from zkemail_rs_amd._abi import Email, PublicKey
 from synth import SignSpec, sign_email
@@ -232,6 +233,58 @@ def build_cases() -> List[Case]:
     c = mk("ext_null", _hdrs(9), _body(100, 2), k0, status=A.ZKE_EXTERNAL_INPUT_NULL, check_inter=False)
     c.email.external_inputs = [A.ExternalInput("name", None, 8)]
     cs.append(c)
+    cs.extend(_mime_cases())
+    return cs
+
+
+def _with_ctype(hs, value: bytes):
+    return [(n, value if n == b"Content-Type" else v) for n, v in hs]
+
+
+def _mime_cases() -> List[Case]:
+    """mailparse's walk over the MIME subparts (core/src/email.rs:26): a malformed subpart header block is the same panic
+    as a malformed top-level one, whatever the signature says; tests/test_mime_walk.py holds the rule-by-rule cases."""
+    cs: List[Case] = []
+    k0 = K()
+    mp = b'multipart/alternative; boundary="=_b0"'
+    good = (b"This is a multi-part message.\r\n--=_b0\r\nContent-Type: text/plain; charset=utf-8\r\n\r\nplain text\r\n"
+            b"--=_b0\r\nContent-Type: text/html;\r\n\tcharset=utf-8\r\nContent-Transfer-Encoding: quoted-printable\r\n\r\n<p>html</p>\r\n--=_b0--\r\n")
+    cs.append(mk("mime_pass_alternative", _with_ctype(_hdrs(11), mp), good, k0))
+    cs.append(mk("mime_subpart_leading_space", _with_ctype(_hdrs(11), mp), good.replace(b"Content-Type: text/plain", b" Content-Type: text/plain"), k0,
+                 status=A.ZKE_PARSE_FAIL, detail=A.D_SUBPART_LEADING_SPACE, check_inter=False))
+    cs.append(mk("mime_subpart_text_without_headers", _with_ctype(_hdrs(11), mp), b"--=_b0\r\nJust some text\r\n that goes on\r\n--=_b0--\r\n", k0,
+                 status=A.ZKE_PARSE_FAIL, detail=A.D_SUBPART_LEADING_SPACE, check_inter=False))
+    cs.append(mk("mime_subpart_lone_cr", _with_ctype(_hdrs(11), mp), good.replace(b"charset=utf-8\r\n\r\nplain", b"charset=utf-8\r\n\rX\r\nplain"), k0,
+                 status=A.ZKE_PARSE_FAIL, detail=A.D_SUBPART_LONE_CR, check_inter=False))
+    cs.append(mk("mime_unterminated_tail_is_not_a_part", _with_ctype(_hdrs(11), mp), b"--=_b0\r\nA: b\r\n\r\nx\r\n--=_b0\r\n never parsed\r\n", k0))
+    cs.append(mk("mime_leaf_body_is_not_walked", _hdrs(11), b"--=_b0\r\n looks bad\r\n--=_b0--\r\n", k0))
+    nested = (b"--=_b0\r\nContent-Type: multipart/related; boundary=inner\r\n\r\n--inner\r\nContent-Type: text/html\r\n\r\n<p>x</p>\r\n"
+              b"--inner\r\nContent-Type: image/png; name=\"=?UTF-8?B?w6k=?=.png\"\r\nContent-ID: <1>\r\n\r\niVBORw0KGgo=\r\n--inner--\r\n--=_b0--\r\n")
+    cs.append(mk("mime_pass_nested", _with_ctype(_hdrs(11), mp), nested, k0))
+    cs.append(mk("mime_nested_leading_space", _with_ctype(_hdrs(11), mp), nested.replace(b"Content-ID: <1>", b"X\r\n folded-onto-nothing"), k0,
+                 status=A.ZKE_PARSE_FAIL, detail=A.D_SUBPART_LEADING_SPACE, check_inter=False))
+    # the part that fails lies beyond the staged head of the e-mail (3.5 KB) and behind a 100-byte boundary
+    longb = b"x" * 100
+    far = b"--" + longb + b"\r\nA: b\r\n\r\n" + _body(5000, 4) + b"\r\n--" + longb + b"\r\n bad\r\n--" + longb + b"--\r\n"
+    cs.append(mk("mime_far_subpart_leading_space", _with_ctype(_hdrs(11), b"multipart/mixed; boundary=" + longb), far, k0,
+                 status=A.ZKE_PARSE_FAIL, detail=A.D_SUBPART_LEADING_SPACE, check_inter=False))
+    cs.append(mk("mime_far_pass", _with_ctype(_hdrs(11), b"multipart/mixed; boundary=" + longb), far.replace(b"\r\n bad\r\n", b"\r\nB: ok\r\n"), k0))
+    # a near miss of the long boundary (differs in its last byte) is not a boundary
+    cs.append(mk("mime_long_boundary_near_miss", _with_ctype(_hdrs(11), b"multipart/mixed; boundary=" + longb),
+                 b"--" + longb[:-1] + b"y\r\n bad\r\n--" + longb + b"\r\nA: b\r\n\r\n--" + longb + b"--\r\n", k0))
+    # the carve-outs are reported
+    cs.append(mk("mime_u_8bit_boundary", _with_ctype(_hdrs(11), b'multipart/mixed; boundary="\xc3\xa9"'), b"--\xc3\xa9\r\n bad\r\n", k0,
+                 status=A.ZKE_UNSUPPORTED, detail=A.D_U_MIME_CTYPE, check_inter=False))
+    cs.append(mk("mime_u_rfc2231_boundary", _with_ctype(_hdrs(11), b"multipart/mixed; boundary*0=ab; boundary*1=cd"), b"--abcd\r\n bad\r\n--abcd--", k0,
+                 status=A.ZKE_UNSUPPORTED, detail=A.D_U_MIME_BOUNDARY, check_inter=False))
+    cs.append(Case("mime_u_depth", Email("example.com", b"From: a@example.com\r\n" + mime_fuzz.deep(9, bad_at=8), PublicKey(k0.pkcs1_der)),
+                   A.ZKE_UNSUPPORTED, A.D_U_MIME_DEPTH, None, check_inter=False))
+    cs.append(Case("mime_depth_8_fails_in_the_leaf", Email("example.com", b"From: a@example.com\r\n" + mime_fuzz.deep(8, bad_at=7), PublicKey(k0.pkcs1_der)),
+                   A.ZKE_PARSE_FAIL, A.D_SUBPART_LEADING_SPACE, None, check_inter=False))
+    # the first Content-Type is the 70th header field (beyond the header table's LDS part)
+    many = [(b"X-Pad-%d" % j, b"v") for j in range(69)] + _with_ctype(_hdrs(11), mp)
+    cs.append(mk("mime_content_type_is_header_77", many, good.replace(b"Content-Type: text/plain", b" Content-Type: text/plain"), k0,
+                 status=A.ZKE_PARSE_FAIL, detail=A.D_SUBPART_LEADING_SPACE, check_inter=False))
     return cs
 
 

@@ -40,6 +40,8 @@ class Oracle:
         lib.zko_b64_decode.restype = C.c_long
         lib.zko_parse_headers.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
         lib.zko_parse_headers.restype = C.c_long
+        lib.zko_mime_walk.argtypes = [vp, C.c_size_t, C.POINTER(C.c_uint32)]
+        lib.zko_mime_walk.restype = C.c_uint32
         lib.zko_canon_body.argtypes = [vp, C.c_size_t, C.c_int, vp]
         lib.zko_canon_body.restype = C.c_size_t
         lib.zko_canon_header.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.c_int, vp]
@@ -120,6 +122,12 @@ class Oracle:
             return int(n), [], 0
         hs = [(raw[spans[4 * i]:spans[4 * i + 1]], raw[spans[4 * i + 2]:spans[4 * i + 3]]) for i in range(n)]
         return int(n), hs, body.value
+
+    def mime_walk(self, raw: bytes):
+        """(status, detail) of mailparse's subpart walk: (0, 0), (ZKE_PARSE_FAIL, D_*) or (ZKE_UNSUPPORTED, D_U_MIME_*)."""
+        d = C.c_uint32()
+        r = self.lib.zko_mime_walk(self._buf(raw), len(raw), C.byref(d))
+        return int(r), int(d.value)
 
     def canon_body(self, body: bytes, relaxed: bool) -> bytes:
         out = (C.c_uint8 * (len(body) + 8))()

@@ -139,6 +139,34 @@ def test_mutation_fuzz_parity(engine, oracle, seed):
     assert_records_equal(got, exp, None, "fuzz")
 
 
+@pytest.mark.parametrize("seed,exotic", [(11, 0.0), (12, 0.2)])
+def test_mime_walk_fuzz_parity(engine, oracle, seed, exotic):
+    """mailparse's walk over the MIME subparts (csrc/mime.hip.h): signed e-mails whose bodies are random multipart trees
+    (tests/mime_fuzz.py: colliding boundaries, every Content-Type spelling, missing terminators, malformed subpart header
+    blocks, byte mutations) — every field of every record as the oracle has it, and every outcome of the walk reached."""
+    import mime_fuzz
+    rng = np.random.default_rng(seed)
+    keys = synth.load_keys()
+    k0 = keys["rsa2048_00"]
+    emails = []
+    for i in range(768):
+        ct, body = mime_fuzz.message(rng, bad=0.12, exotic=exotic, mutate=0.25)
+        hs = [(n, v) for n, v in synth.std_headers(rng, i, "example.com") if n != b"Content-Type"]
+        if ct is not None:
+            hs.insert(int(rng.integers(0, len(hs) + 1)), (b"Content-Type", ct))
+        if rng.random() < 0.3:                     # pad the body so that parts lie beyond the staged head of the e-mail
+            body = body + synth.ascii_body(rng, int(rng.integers(100, 6000)))
+        raw, _ = synth.sign_email(hs, body, k0, SignSpec(header_canon="relaxed", body_canon="relaxed" if i % 2 else "simple"))
+        emails.append(A.Email("example.com", raw, A.PublicKey(k0.pkcs1_der)))
+    got, exp, d1, d2 = run_both(engine, oracle, emails)
+    assert_records_equal(got, exp, None, "mime fuzz")
+    seen = set((int(r["status"]), int(r["detail"])) for r in exp)
+    assert (A.ZKE_OK, 0) in seen and (A.ZKE_PARSE_FAIL, A.D_SUBPART_LEADING_SPACE) in seen and (A.ZKE_PARSE_FAIL, A.D_SUBPART_LONE_CR) in seen
+    if exotic:
+        assert (A.ZKE_UNSUPPORTED, A.D_U_MIME_CTYPE) in seen and (A.ZKE_UNSUPPORTED, A.D_U_MIME_BOUNDARY) in seen
+    assert (exp["status"] == 0).sum() > 300
+
+
 def test_header_folds_at_every_chunk_offset(engine, oracle):
     """The wave scans header values 64 bytes per step: put the CRLF of a folded line, WSP runs and the end of the
     value at every offset modulo 64 (both canonicalisations), signed by the Python signer — every e-mail must

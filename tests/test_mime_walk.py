@@ -1,0 +1,113 @@
+"""mailparse's MIME subpart walk (parse_mail_recursive, call site core/src/email.rs:26): the oracle's restatement against
+an independent Python statement of the same crate behaviour (tests/mime_model.py), on hand-written cases and on random
+multipart trees.  The engine's answer may be ZKE_UNSUPPORTED only for the stated carve-outs."""
+import numpy as np
+import pytest
+
+import mime_fuzz
+import mime_model
+import oracle_lib
+from zkemail_rs_amd import _abi as A
+
+
+@pytest.fixture(scope="module")
+def orc():
+    return oracle_lib.load()
+
+
+def expect(v):
+    """model verdict -> (status, detail) of the engine's record"""
+    if v[0] == "ok":
+        return (0, 0)
+    if v[0] == "fail":
+        what, depth = v[1], v[2]
+        if what == "leading space":
+            return (A.ZKE_PARSE_FAIL, A.D_HDR_LEADING_SPACE if depth == 0 else A.D_SUBPART_LEADING_SPACE)
+        return (A.ZKE_PARSE_FAIL, A.D_HDR_LONE_CR if depth == 0 else A.D_SUBPART_LONE_CR)
+    return None
+
+
+H = b"From: a@b\r\nContent-Type: multipart/mixed; boundary=\"xx\"\r\n\r\n"
+CASES = [
+    # (name, raw, expected (status, detail))
+    ("leaf", b"Content-Type: text/plain\r\n\r\n--xx\r\n bad\r\n--xx--\r\n", (0, 0)),
+    ("no_content_type", b"From: a\r\n\r\n--xx\r\n bad\r\n--xx--\r\n", (0, 0)),
+    ("good_two_parts", H + b"pre\r\n--xx\r\nA: b\r\n\r\nhello\r\n--xx\r\nC: d\r\n\r\n\r\n--xx--\r\n", (0, 0)),
+    ("part_starts_with_space", H + b"--xx\r\n bad\r\n--xx--\r\n", (A.ZKE_PARSE_FAIL, A.D_SUBPART_LEADING_SPACE)),
+    ("space_after_colonless_line", H + b"--xx\r\nhello world\r\n more\r\n--xx--\r\n", (A.ZKE_PARSE_FAIL, A.D_SUBPART_LEADING_SPACE)),
+    ("tab_after_colonless_line_is_a_key", H + b"--xx\r\nhello world\r\n\tmore\r\n--xx--\r\n", (0, 0)),
+    ("space_continues_a_value", H + b"--xx\r\nA: b\r\n more\r\n\r\n--xx--\r\n", (0, 0)),
+    ("lone_cr", H + b"--xx\r\nA: b\r\n\rX\r\n--xx--\r\n", (A.ZKE_PARSE_FAIL, A.D_SUBPART_LONE_CR)),
+    ("unterminated_last_part_is_not_walked", H + b"--xx\r\nA: b\r\n\r\nok\r\n--xx\r\n bad\r\n", (0, 0)),
+    ("after_the_terminator_is_not_walked", H + b"--xx\r\nA: b\r\n\r\n--xx--\r\n--xx\r\n bad\r\n--xx--\r\n", (0, 0)),
+    ("boundary_must_start_a_line", H + b"text --xx\r\n bad\r\n--xx--\r\n", (0, 0)),
+    ("boundary_is_a_prefix_test", H + b"--xxx\r\n bad\r\n--xx--\r\n", (A.ZKE_PARSE_FAIL, A.D_SUBPART_LEADING_SPACE)),
+    ("part_begins_after_the_next_lf", H + b"--xx junk \r\n bad\r\n--xx--\r\n", (A.ZKE_PARSE_FAIL, A.D_SUBPART_LEADING_SPACE)),
+    ("empty_part", H + b"--xx\r\n--xx\r\n--xx--\r\n", (0, 0)),
+    ("no_body", b"Content-Type: multipart/mixed; boundary=xx\r\n\r\n", (0, 0)),
+    ("first_content_type_wins", b"Content-Type: text/plain\r\nContent-Type: multipart/mixed; boundary=xx\r\n\r\n--xx\r\n bad\r\n--xx--\r\n", (0, 0)),
+    ("colonless_content_type_line_wins", b"Content-Type\nContent-Type: multipart/mixed; boundary=xx\r\n\r\n--xx\r\n bad\r\n--xx--\r\n", (0, 0)),
+    ("key_with_trailing_space_is_another_key", b"Content-Type : multipart/mixed; boundary=xx\r\n\r\n--xx\r\n bad\r\n--xx--\r\n", (0, 0)),
+    ("case_insensitive_names", b"CONTENT-type: MULTIPART/Mixed; BOUNDARY=xx\r\n\r\n--xx\r\n bad\r\n--xx--\r\n", (A.ZKE_PARSE_FAIL, A.D_SUBPART_LEADING_SPACE)),
+    ("unquoted_trimmed", b"Content-Type: multipart/mixed; boundary = xx \r\n\r\n--xx\r\n bad\r\n--xx--\r\n", (A.ZKE_PARSE_FAIL, A.D_SUBPART_LEADING_SPACE)),
+    ("folded_before_the_parameter", b"Content-Type: multipart/mixed;\r\n\tboundary=\"xx\"\r\n\r\n--xx\r\n bad\r\n--xx--\r\n", (A.ZKE_PARSE_FAIL, A.D_SUBPART_LEADING_SPACE)),
+    ("last_duplicate_wins", b"Content-Type: multipart/mixed; boundary=yy; boundary=xx\r\n\r\n--xx\r\n bad\r\n--xx--\r\n", (A.ZKE_PARSE_FAIL, A.D_SUBPART_LEADING_SPACE)),
+    ("last_duplicate_wins_2", b"Content-Type: multipart/mixed; boundary=xx; boundary=yy\r\n\r\n--xx\r\n bad\r\n--xx--\r\n", (0, 0)),
+    ("semicolon_in_quotes_still_splits", b"Content-Type: multipart/mixed; boundary=\"x;x\"\r\n\r\n--\"x\r\n bad\r\n--\"x--\r\n", (A.ZKE_PARSE_FAIL, A.D_SUBPART_LEADING_SPACE)),
+    ("single_quote_char_value", b"Content-Type: multipart/mixed; boundary=\"\r\n\r\n--\"\r\n bad\r\n--\"--\r\n", (A.ZKE_PARSE_FAIL, A.D_SUBPART_LEADING_SPACE)),
+    ("empty_boundary", b"Content-Type: multipart/mixed; boundary=\"\"\r\n\r\n--\r\n bad\r\n--\r\n", (A.ZKE_PARSE_FAIL, A.D_SUBPART_LEADING_SPACE)),
+    ("multipart_needs_the_slash", b"Content-Type: multipart; boundary=xx\r\n\r\n--xx\r\n bad\r\n--xx--\r\n", (0, 0)),
+    ("no_boundary_parameter", b"Content-Type: multipart/mixed; bound=xx\r\n\r\n--xx\r\n bad\r\n--xx--\r\n", (0, 0)),
+    ("nested", H + b"--xx\r\nContent-Type: multipart/alternative; boundary=yy\r\n\r\n--yy\r\n bad\r\n--yy--\r\n--xx--\r\n", (A.ZKE_PARSE_FAIL, A.D_SUBPART_LEADING_SPACE)),
+    ("nested_inner_boundary_beyond_the_part", H + b"--xx\r\nContent-Type: multipart/alternative; boundary=yy\r\n\r\n--yy\r\nA: b\r\n\r\n--xx\r\nX: y\r\n\r\n--yy\r\n bad\r\n--yy--\r\n--xx--\r\n", (0, 0)),
+    ("a_part_that_begins_with_a_foreign_boundary_line", H + b"--xx\r\n--yy\r\n bad\r\n--yy--\r\n--xx--\r\n", (A.ZKE_PARSE_FAIL, A.D_SUBPART_LEADING_SPACE)),
+    ("nested_same_boundary", H + b"--xx\r\nContent-Type: multipart/alternative; boundary=xx\r\n\r\n--xx--\r\n", (0, 0)),
+    ("message_rfc822_is_a_leaf", H + b"--xx\r\nContent-Type: message/rfc822\r\n\r\nContent-Type: multipart/mixed; boundary=yy\r\n\r\n--yy\r\n bad\r\n--yy--\r\n--xx--\r\n", (0, 0)),
+    ("leaf_with_encoded_word", H + b"--xx\r\nContent-Type: application/pdf; name=\"=?UTF-8?B?w6k=?=\"\r\n\r\n--xx--\r\n", (0, 0)),
+    ("leaf_with_8bit_after_first_token", H + b"--xx\r\nContent-Type: text/plain; name=\"\xc3\xa9\"\r\n\r\n--xx--\r\n", (0, 0)),
+    # carve-outs: reported, never guessed
+    ("u_encoded_word_in_first_token", b"Content-Type: =?utf-8?q?multipart/mixed?=; boundary=xx\r\n\r\n--xx\r\n bad\r\n--xx--\r\n", (A.ZKE_UNSUPPORTED, A.D_U_MIME_CTYPE)),
+    ("u_encoded_word_in_multipart", b"Content-Type: multipart/mixed; boundary=xx; x=\"=?utf-8?q?a?=\"\r\n\r\n--xx\r\n bad\r\n--xx--\r\n", (A.ZKE_UNSUPPORTED, A.D_U_MIME_CTYPE)),
+    ("u_8bit_in_first_token", b"Content-Type: \xc2\xa0multipart/mixed; boundary=xx\r\n\r\n--xx\r\n bad\r\n--xx--\r\n", (A.ZKE_UNSUPPORTED, A.D_U_MIME_CTYPE)),
+    ("u_8bit_in_multipart", b"Content-Type: multipart/mixed; boundary=\"x\xc3\xa9\"\r\n\r\n--x\xc3\xa9\r\n bad\r\n", (A.ZKE_UNSUPPORTED, A.D_U_MIME_CTYPE)),
+    ("u_folded_boundary", b"Content-Type: multipart/mixed; boundary=\"x\r\n x\"\r\n\r\n--x x\r\n bad\r\n--x x--\r\n", (A.ZKE_UNSUPPORTED, A.D_U_MIME_BOUNDARY)),
+    ("u_rfc2231_only", b"Content-Type: multipart/mixed; boundary*0=x; boundary*1=x\r\n\r\n--xx\r\n bad\r\n--xx--\r\n", (A.ZKE_UNSUPPORTED, A.D_U_MIME_BOUNDARY)),
+    ("rfc2231_beside_plain_is_ignored", b"Content-Type: multipart/mixed; boundary*=us-ascii''yy; boundary=xx\r\n\r\n--xx\r\n bad\r\n--xx--\r\n", (A.ZKE_PARSE_FAIL, A.D_SUBPART_LEADING_SPACE)),
+    ("depth_8_walked", mime_fuzz.deep(8, bad_at=7), (A.ZKE_PARSE_FAIL, A.D_SUBPART_LEADING_SPACE)),
+    ("u_depth_9", mime_fuzz.deep(9, bad_at=8), (A.ZKE_UNSUPPORTED, A.D_U_MIME_DEPTH)),
+]
+
+
+@pytest.mark.parametrize("name,raw,want", CASES, ids=[c[0] for c in CASES])
+def test_cases(orc, name, raw, want):
+    got = orc.mime_walk(raw)
+    assert got == want, (name, got, want)
+    m = expect(mime_model.verdict(raw))
+    if want[0] != A.ZKE_UNSUPPORTED:
+        assert m == want, (name, m, want)                  # the model agrees wherever the engine gives an answer
+    elif name == "u_depth_9":
+        assert m == (A.ZKE_PARSE_FAIL, A.D_SUBPART_LEADING_SPACE)      # ... and shows what was not decided
+
+
+@pytest.mark.parametrize("seed,exotic", [(1, 0.0), (2, 0.0), (3, 0.25)])
+def test_random_trees_against_the_model(orc, seed, exotic):
+    rng = np.random.default_rng(seed)
+    n = 4000
+    outcomes = {}
+    unsupported = 0
+    for _ in range(n):
+        raw = mime_fuzz.standalone(rng, bad=0.15, exotic=exotic, mutate=0.3)
+        got = orc.mime_walk(raw)
+        want = expect(mime_model.verdict(raw))
+        if got[0] == A.ZKE_UNSUPPORTED:
+            unsupported += 1
+            # plain trees: only a mutation's LF inside a boundary value, or the generator's unterminated "=?"
+            assert exotic > 0 or got[1] == A.D_U_MIME_BOUNDARY or b"=?" in raw, raw
+            continue
+        assert want is not None, raw                  # the model is undecided only where the engine is
+        assert got == want, (raw, got, want)
+        outcomes[got] = outcomes.get(got, 0) + 1
+    assert outcomes.get((0, 0), 0) > n // 4
+    assert outcomes.get((A.ZKE_PARSE_FAIL, A.D_SUBPART_LEADING_SPACE), 0) > 50
+    assert outcomes.get((A.ZKE_PARSE_FAIL, A.D_SUBPART_LONE_CR), 0) > 20
+    assert unsupported < (n // 3 if exotic else n // 20)       # plain trees: a tab-led junk line that continues the Content-Type value

@@ -54,6 +54,8 @@ D_SIG_B64 = 12
 D_SIG_MISMATCH = 13
 D_HDR_LEADING_SPACE = 20
 D_HDR_LONE_CR = 21
+D_SUBPART_LEADING_SPACE = 23
+D_SUBPART_LONE_CR = 24
 D_KEY_TYPE = 30
 D_KEY_DER = 31
 D_KEY_RANGE = 32
@@ -75,6 +77,9 @@ D_U_SIG_TOO_LONG = 63
 D_U_TOO_MANY_SIGS = 64
 D_U_SIG_B_REPEATED = 65
 D_U_DOMAIN_FOLD = 66
+D_U_MIME_CTYPE = 67
+D_U_MIME_BOUNDARY = 68
+D_U_MIME_DEPTH = 69
 
 KEY_RSA, KEY_ED25519, KEY_OTHER = 0, 1, 2
 F_HDR_RELAXED, F_BODY_RELAXED, F_HAS_LENGTH, F_SHA1, F_ED25519 = 1, 2, 4, 8, 16

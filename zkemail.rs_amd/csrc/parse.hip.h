@@ -2,8 +2,8 @@
 // wavefront (blockDim = 64).
 //
 // Replaces, on the verify path (call sites core/src/email.rs:26-33, core/src/circuits.rs:34-35):
-//   * mailparse 0.15.0 parse_headers / parse_header (header list; the MIME subpart walk has no
-//     effect on this path other than extra parse errors on malformed subparts — not restated);
+//   * mailparse 0.15.0 parse_headers / parse_header (header list) and parse_mail_recursive's walk over the MIME
+//     subparts (mime.hip.h: its only effect on this path is the parse error of a malformed subpart header block);
 //   * cfdkim validate_header, the tag-list grammar (RFC 6376 §3.2), d= / i= / h= / q= / v= checks,
 //     c= / a= / l= parsing, header selection (§5.4.2, bottom-up) and header canonicalisation
 //     (§3.4.1 / §3.4.2) producing the header-hash preimage (§3.7);
@@ -438,8 +438,10 @@ __device__ __forceinline__ bool parse_usize_tag(const ParseLds& L, int id, uint6
 }
 
 // ------------------------------------------------------------------ mailparse header split
-// Fills L.hdr; returns the header count or NONE with *perr set.
-__device__ __forceinline__ uint32_t split_headers(ParseLds& L, uint32_t* ovf, const Str& raw, uint32_t& perr, uint32_t& hdr_end) {
+// parse_headers / parse_header over `raw`: sink(ix, key_end, vs, ve) for every header field (false = stop: too many).
+// Returns the header count or NONE with perr set; hdr_end = where the list stopped (the empty line, or the end).
+template <class Sink>
+__device__ __forceinline__ uint32_t scan_headers(const Str& raw, uint32_t& perr, uint32_t& hdr_end, Sink sink) {
   Win w; w.wpos = WNONE; w.c = 0;
   const uint32_t len = raw.len;
   uint32_t ix = 0, nh = 0;
@@ -477,15 +479,25 @@ __device__ __forceinline__ uint32_t split_headers(ParseLds& L, uint32_t* ovf, co
       const uint32_t lastv = wrfind(raw, w, vs, lim, [](uint32_t c) { return c != '\r' && c != '\n'; });
       ve = (lastv == NONE) ? vs : lastv + 1;
     }
-    if (nh >= ZKE_MAX_HEADERS) { perr = ZKE_D_U_TOO_MANY_HEADERS; return NONE; }
-    hdr_put(L, ovf, nh, ix, key_end, vs, ve);
+    if (!sink(ix, key_end, vs, ve)) { perr = ZKE_D_U_TOO_MANY_HEADERS; return NONE; }
     nh++;
     ix = next;
   }
-  hdr_end = ix;                       // where the header list stopped: the empty line, or the end of the input
+  hdr_end = ix;
+  return nh;
+}
+// Fills L.hdr; returns the header count or NONE with perr set.
+__device__ __forceinline__ uint32_t split_headers(ParseLds& L, uint32_t* ovf, const Str& raw, uint32_t& perr, uint32_t& hdr_end) {
+  uint32_t nh = 0;
+  const uint32_t r = scan_headers(raw, perr, hdr_end, [&](uint32_t ix, uint32_t key_end, uint32_t vs, uint32_t ve) {
+    if (nh >= ZKE_MAX_HEADERS) return false;
+    hdr_put(L, ovf, nh, ix, key_end, vs, ve);
+    nh++;
+    return true;
+  });
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  return nh;
+  return r;
 }
 
 // The same split for a header block that lies inside the staged head (every ordinary e-mail), as one streaming pass:
@@ -742,6 +754,10 @@ __device__ __forceinline__ bool same_bytes(const Str& v, uint32_t p, uint32_t a,
   return true;
 }
 
+}  // namespace zke
+#include "mime.hip.h"
+namespace zke {
+
 // ------------------------------------------------------------------ the parse kernel
 // mode 0: verify_email_with_key scan (round r picks the r-th same-domain candidate)
 // mode 1: canonicalize_signed_email (first DKIM-Signature header, no domain filter; core/src/circuits.rs:34-35)
@@ -854,6 +870,29 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
     if (A.mode == 0) { R->n_headers = nh; R->body_offset = body_off; }
     M->n_headers = nh; M->body_off = body_off; M->body_len = raw.len - body_off;
   }
+  // lane x: where header field x's name starts and how long it is (fields 0..63; later ones are looked up one by one)
+  uint32_t hks_lane = 0, hnl_lane = NONE;
+  if ((uint32_t)lane < nh && lane < (int)HDR_LDS_ENTRIES) { hks_lane = L.hdr[4 * lane]; hnl_lane = L.hdr[4 * lane + 1] - hks_lane; }
+  if (round == 0 && A.mode == 0) {
+    // ---- still parse_mail: the MIME subparts (mime.hip.h).  The first Content-Type header of the message decides.
+    bool has_ct = false;
+    uint32_t cvs = 0, cve = 0;
+    for (uint64_t m = __ballot(hnl_lane == 12u); m; m &= m - 1) {
+      const uint32_t x = (uint32_t)__builtin_ctzll(m);
+      if (span_ieq(raw, __builtin_amdgcn_readlane(hks_lane, x), 12, CT_NAME, 12)) { const HdrSpan hs = hdr_get(L, hdr_ovf, x); has_ct = true; cvs = hs.vs; cve = hs.ve; break; }
+    }
+    for (uint32_t x = HDR_LDS_ENTRIES; !has_ct && x < nh; x++) {
+      const HdrSpan hs = hdr_get(L, hdr_ovf, x);
+      if (span_ieq(raw, hs.ks, hs.ke - hs.ks, CT_NAME, 12)) { has_ct = true; cvs = hs.vs; cve = hs.ve; }
+    }
+    if (has_ct) {
+      uint32_t ixb = hdr_end;                      // behind the empty line that ended the header list
+      if (ixb < raw.len) ixb += (uni(ldb(raw, ixb)) == '\r') ? 2u : 1u;
+      uint32_t md = 0;
+      const uint32_t mr = mime_walk((uint32_t*)L.tagbuf, raw, ixb, true, cvs, cve, md);     // the tag buffer is not in use yet
+      if (mr) { finish(mr, md); return; }
+    }
+  }
 
   // ---- DkimPublicKey::try_from_bytes (core/src/email.rs:28-29)
   if (round == 0 && A.mode == 0) {
@@ -897,9 +936,6 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
   uint32_t first_sig_hdr = NONE;
   uint32_t cand_flags = 0;
   uint64_t cand_len_tag = 0;
-  // lane x: where header field x's name starts and how long it is (fields 0..63; later ones are looked up one by one)
-  uint32_t hks_lane = 0, hnl_lane = NONE;
-  if ((uint32_t)lane < nh && lane < (int)HDR_LDS_ENTRIES) { hks_lane = L.hdr[4 * lane]; hnl_lane = L.hdr[4 * lane + 1] - hks_lane; }
   const uint64_t sig_len_mask = __ballot(hnl_lane == 14u);          // only a 14-byte name can be "DKIM-Signature"
   for (uint32_t hx = 0; hx < nh; hx++) {
     if (hx < 64 && !((sig_len_mask >> hx) & 1)) continue;
