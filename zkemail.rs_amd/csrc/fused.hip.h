@@ -29,8 +29,11 @@ struct StageArgs {
 
 constexpr uint32_t QUAD_LDS_DWORDS = 16 * (4 * QL + 4), OCT_LDS_DWORDS = 8 * (8 * QL + 4);      // per wave
 
+#ifndef ZKE_STAGE_WAVES
+#define ZKE_STAGE_WAVES 2        // waves per SIMD the hash / modexp launch is compiled for
+#endif
 template <int T>
-__global__ __launch_bounds__(128) void hash_modexp_kernel(StageArgs A) {
+__global__ __launch_bounds__(128, ZKE_STAGE_WAVES) void hash_modexp_kernel(StageArgs A) {
   static_assert(sha256_pair_lds_bytes<T>() >= 2 * 4 * QUAD_LDS_DWORDS && sha256_pair_lds_bytes<T>() >= 2 * 4 * OCT_LDS_DWORDS,
                 "the RSA roles borrow the launch's LDS");
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];

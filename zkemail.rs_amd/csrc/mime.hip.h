@@ -20,9 +20,6 @@
 namespace zke {
 
 constexpr uint32_t MIME_MAX_DEPTH = 8;
-__device__ const uint8_t CT_NAME[12] = {'c', 'o', 'n', 't', 'e', 'n', 't', '-', 't', 'y', 'p', 'e'};
-__device__ const uint8_t MULTIPART_LIT[10] = {'m', 'u', 'l', 't', 'i', 'p', 'a', 'r', 't', '/'};
-__device__ const uint8_t BOUNDARY_LIT[9] = {'b', 'o', 'u', 'n', 'd', 'a', 'r', 'y', '*'};
 
 __device__ __forceinline__ bool rust_ws(uint32_t c) { return c == ' ' || (c >= 9 && c <= 13); }     // ASCII members of White_Space
 
@@ -48,13 +45,33 @@ __device__ __forceinline__ void mime_trim(const Str& v, Win& w, uint32_t& s, uin
 // parse_content_type(get_value()) as far as the walk needs it.  0: no multipart with a boundary; 1: the boundary value is
 // v[bs, be); 0x80000000 | ZKE_D_U_MIME_*: not decided
 __device__ __forceinline__ uint32_t mime_content_type(const Str& v, uint32_t& bs, uint32_t& be) {
-  Win w; w.wpos = WNONE; w.c = 0;
   const uint32_t n = v.len;
+  {
+    // The usual case in one look at the first 64 bytes: the first token ends there (';' or the end of the value), holds
+    // nothing undecidable and does not start with "multipart/" — a leaf.
+    const uint32_t l = (uint32_t)lane_id();
+    const uint32_t c = ldb(v, l);
+    const uint64_t semi = __ballot(c == ';');
+    const uint32_t t0 = semi ? (uint32_t)__builtin_ctzll(semi) : (n <= 64 ? n : 65u);
+    if (t0 <= 63) {                                                       // (a token that fills the chunk goes the long way)
+      const uint32_t nx = lane_shl1(c);                                   // lane 63 is outside the token
+      const bool in = l < t0;
+      const uint64_t und = __ballot(in && (c >= 0x80 || (c == '=' && nx == '?')));
+      const uint64_t nws = __ballot(in && !rust_ws(c));
+      if (!und) {
+        if (!nws) return 0;
+        const uint32_t s0 = (uint32_t)__builtin_ctzll(nws), e0 = 64u - (uint32_t)__builtin_clzll(nws);
+        if (e0 - s0 < 10) return 0;
+        if (__ballot(l >= s0 && l < s0 + 10 && lower(c) != lit_at(LIT("multipart/"), l - s0))) return 0;
+      }
+    }
+  }
+  Win w; w.wpos = WNONE; w.c = 0;
   const uint32_t t0e = wfind(v, w, 0, n, [](uint32_t c) { return c == ';'; });
   if (mime_undecidable(v, 0, t0e)) return 0x80000000u | ZKE_D_U_MIME_CTYPE;
   uint32_t s = 0, e = t0e;
   mime_trim(v, w, s, e);
-  if (e - s < 10 || !span_ieq(v, s, 10, MULTIPART_LIT, 10)) return 0;
+  if (e - s < 10 || !span_ieq(v, s, 10, LIT("multipart/"))) return 0;
   if (mime_undecidable(v, 0, n)) return 0x80000000u | ZKE_D_U_MIME_CTYPE;
   bool have = false, starred = false;
   for (uint32_t p = t0e + 1; p <= n;) {
@@ -65,8 +82,8 @@ __device__ __forceinline__ uint32_t mime_content_type(const Str& v, uint32_t& bs
       mime_trim(v, w, ks, ke);
       mime_trim(v, w, vs, ve);
       if (ve - vs > 1 && at(v, w, vs) == '"' && at(v, w, ve - 1) == '"') { vs++; ve--; }
-      if (ke - ks == 8 && span_ieq(v, ks, 8, BOUNDARY_LIT, 8)) { have = true; bs = vs; be = ve; }
-      else if (ke - ks >= 9 && span_ieq(v, ks, 9, BOUNDARY_LIT, 9)) starred = true;
+      if (ke - ks == 8 && span_ieq(v, ks, 8, LIT("boundary"))) { have = true; bs = vs; be = ve; }
+      else if (ke - ks >= 9 && span_ieq(v, ks, 9, LIT("boundary*"))) starred = true;
     }
     if (q >= n) break;
     p = q + 1;
@@ -148,7 +165,7 @@ __device__ __forceinline__ uint32_t mime_walk(uint32_t* stk, const Str& raw, uin
     uint32_t perr = 0, hdr_end = 0, cvs = 0, cve = 0;
     bool ct = false;
     const uint32_t nh = scan_headers(sub, perr, hdr_end, [&](uint32_t ix, uint32_t key_end, uint32_t vs, uint32_t ve) {
-      if (!ct && key_end - ix == 12 && span_ieq(sub, ix, 12, CT_NAME, 12)) { ct = true; cvs = vs; cve = ve; }
+      if (!ct && key_end - ix == 12 && span_ieq(sub, ix, 12, LIT("content-type"))) { ct = true; cvs = vs; cve = ve; }
       return true;
     });
     if (nh == NONE) {

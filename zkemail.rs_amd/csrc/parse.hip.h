@@ -205,12 +205,38 @@ __device__ __forceinline__ bool span_ieq(const Str& s, uint32_t a, uint32_t n, c
 __device__ __forceinline__ uint32_t lane_shl1(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130 /*wave_shl:1: lane l <- l+1*/, 0xf, 0xf, false); }
 __device__ __forceinline__ uint32_t lane_shr1(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138 /*wave_shr:1: lane l <- l-1*/, 0xf, 0xf, false); }
 
+// Short literals (<= 16 bytes) as four constant words: byte `lane` of one comes out of two v_perm_b32 on constants —
+// no per-lane load from constant memory (a dependent L2 round trip per comparison) and no hoisted per-lane address of
+// every literal (two registers each, live across the whole signature loop: they were what the front end spilled).
+struct Lit { uint32_t w0, w1, w2, w3, n; };
+template <size_t N>
+constexpr Lit LIT(const char (&s)[N]) {
+  static_assert(N >= 1 && N - 1 <= 16, "literal too long");
+  uint32_t w[4] = {0, 0, 0, 0};
+  for (size_t i = 0; i + 1 < N; i++) w[i / 4] |= (uint32_t)(uint8_t)s[i] << (8 * (i % 4));
+  return Lit{w[0], w[1], w[2], w[3], (uint32_t)(N - 1)};
+}
+__device__ __forceinline__ uint32_t lit_at(const Lit& t, uint32_t lane) {      // byte `lane` (< 16) of the literal
+  const uint32_t sel = (lane & 7u) | 0x0c0c0c00u;
+  const uint32_t lo = __builtin_amdgcn_perm(t.w1, t.w0, sel);
+  if (t.n <= 8) return lo;
+  const uint32_t hi = __builtin_amdgcn_perm(t.w3, t.w2, sel);
+  return (lane & 8u) ? hi : lo;
+}
+// case-insensitive equality of s[a, a+n) with a lower-case literal
+__device__ __forceinline__ bool span_ieq(const Str& s, uint32_t a, uint32_t n, const Lit& t) {
+  if (n != t.n) return false;
+  const uint32_t l = (uint32_t)lane_id();
+  const bool bad = l < n && lower(ldb(s, a + l)) != lit_at(t, l);
+  return __ballot(bad) == 0;
+}
+
 // ------------------------------------------------------------------ output stream (preimage)
 struct Out { uint8_t* p; uint32_t o, cap; bool overflow; };
-__device__ __forceinline__ void emit_lit(Out& out, const char* lit, uint32_t n) {
-  if (out.o + n > out.cap) { out.overflow = true; return; }
-  if ((uint32_t)lane_id() < n) out.p[out.o + lane_id()] = (uint8_t)lit[lane_id()];
-  out.o += n;
+__device__ __forceinline__ void emit_lit(Out& out, const Lit& t) {
+  if (out.o + t.n > out.cap) { out.overflow = true; return; }
+  if ((uint32_t)lane_id() < t.n) out.p[out.o + lane_id()] = (uint8_t)lit_at(t, (uint32_t)lane_id());
+  out.o += t.n;
 }
 template <class F>   // copy s[a,b) through a byte map
 __device__ __forceinline__ void emit_map(Out& out, const Str& s, uint32_t a, uint32_t b, F f) {
@@ -274,14 +300,14 @@ __device__ __forceinline__ void emit_header(Out& out, const Str& key, const Str&
     uint32_t ke = wrfind(key, w, 0, key.len, [](uint32_t c) { return !is_wsp(c); });
     ke = (ke == NONE) ? 0 : ke + 1;
     emit_map(out, key, 0, ke, [](uint32_t c) { return lower(c); });
-    emit_lit(out, ":", 1);
+    emit_lit(out, LIT(":"));
     emit_relaxed_value(out, val);
   } else {
     emit_map(out, key, 0, key.len, [](uint32_t c) { return c; });
-    emit_lit(out, ": ", 2);
+    emit_lit(out, LIT(": "));
     emit_map(out, val, 0, val.len, [](uint32_t c) { return c; });
   }
-  if (crlf) emit_lit(out, "\r\n", 2);
+  if (crlf) emit_lit(out, LIT("\r\n"));
 }
 
 // ------------------------------------------------------------------ LDS image of one wave
@@ -327,12 +353,19 @@ __device__ __forceinline__ bool strip_to_lds(ParseLds& L, const Str& v, uint32_t
   return true;
 }
 __device__ __forceinline__ uint32_t tagf(const ParseLds& L, int id, int k) { return uni(L.tag[id][k]); }    // k: 0 raw_s, 1 raw_e, 2 val_off, 3 val_len
-__device__ __forceinline__ bool tagval_eq(const ParseLds& L, int id, const char* lit, uint32_t n) {
-  if (tagf(L, id, 3) != n) return false;
-  bool bad = false;
-  if ((uint32_t)lane_id() < n) bad = L.tagbuf[tagf(L, id, 2) + lane_id()] != (uint8_t)lit[lane_id()];
-  return __ballot(bad) == 0;
+// a tag's stripped value, first 16 bytes: lane l holds byte l; compared with literals without touching memory again
+struct TagVal { uint32_t len, c; };
+__device__ __forceinline__ TagVal tagval(const ParseLds& L, int id) {
+  TagVal v{tagf(L, id, 3), 0};
+  if ((uint32_t)lane_id() < v.len && lane_id() < 16) v.c = L.tagbuf[tagf(L, id, 2) + lane_id()];
+  return v;
 }
+__device__ __forceinline__ bool operator==(const TagVal& v, const Lit& t) {
+  if (v.len != t.n) return false;
+  const uint32_t l = (uint32_t)lane_id();
+  return __ballot(l < t.n && v.c != lit_at(t, l)) == 0;
+}
+__device__ __forceinline__ bool tagval_eq(const ParseLds& L, int id, const Lit& t) { return tagval(L, id) == t; }
 
 // tag-spec = [FWS] tag-name [FWS] "=" [FWS] tag-value [FWS]   (cfdkim parser::tag_spec)
 // returns the position after the spec, or NONE.  err: 0 ok, else ZKE_D_U_*
@@ -389,7 +422,7 @@ __device__ __forceinline__ uint32_t validate_sig(ParseLds& L, const Str& v, uint
   __builtin_amdgcn_wave_barrier();
   const uint32_t req = (1u << TG_V) | (1u << TG_A) | (1u << TG_B) | (1u << TG_BH) | (1u << TG_D) | (1u << TG_H) | (1u << TG_S);
   if ((present & req) != req) return ZKE_D_MISSING_TAG;
-  if (!tagval_eq(L, TG_V, "1", 1)) return ZKE_D_INCOMPATIBLE_VERSION;
+  if (!tagval_eq(L, TG_V, LIT("1"))) return ZKE_D_INCOMPATIBLE_VERSION;
   if (present & (1u << TG_I)) {   // user.ends_with(signing_domain)
     const uint32_t il = tagf(L, TG_I, 3), dl = tagf(L, TG_D, 3), io = tagf(L, TG_I, 2), dofs = tagf(L, TG_D, 2);
     if (il < dl) return ZKE_D_DOMAIN_MISMATCH;
@@ -414,7 +447,7 @@ __device__ __forceinline__ uint32_t validate_sig(ParseLds& L, const Str& v, uint
     }
     if (!__ballot(found)) return ZKE_D_FROM_NOT_SIGNED;
   }
-  if ((present & (1u << TG_Q)) && !tagval_eq(L, TG_Q, "dns/txt", 7)) return ZKE_D_BAD_QUERY_METHOD;
+  if ((present & (1u << TG_Q)) && !tagval_eq(L, TG_Q, LIT("dns/txt"))) return ZKE_D_BAD_QUERY_METHOD;
   return 0;
 }
 
@@ -500,97 +533,122 @@ __device__ __forceinline__ uint32_t split_headers(ParseLds& L, uint32_t* ovf, co
   return r;
 }
 
-// The same split for a header block that lies inside the staged head (every ordinary e-mail), as one streaming pass:
-// per 64-byte chunk three ballots — ':' bytes, LF bytes, and LFs that end a header (successor not SP / HTAB) — and
-// then only bit scans and a few single-byte reads per header, instead of half a dozen window searches per header
-// (2.6 k of the front end's 10 k scalar instructions per e-mail went into the search bookkeeping of the split).
-// Returns false without side effects that matter when the block runs past the staged bytes: the caller then runs
-// split_headers above.
-__device__ __forceinline__ bool split_headers_staged(ParseLds& L, uint32_t* ovf, const Str& raw, uint32_t& nh_out, uint32_t& perr,
-                                                     uint32_t& hdr_end) {
+// The same split for a header block that lies inside the staged head (every ordinary e-mail), LINE-parallel: the serial
+// form walked the block header by header with a handful of dependent single-byte LDS reads each (2.5 k of the front end's
+// 9 k scalar instructions per e-mail, 22 % of its cycles).
+//   pass A, 64 bytes per step: ballots of LF and ':'; every LF lane stores its position under its line number, every
+//   lane holding the FIRST ':' of its line stores that; stops at the first empty line (LF followed by LF or CRLF), which
+//   ends the header list whatever the state (an empty line never starts with SP / HTAB).
+//   pass B, 64 lines per step, one lane per line: W = the line starts with SP / HTAB, C = it holds a ':'.  "Inside a
+//   value after line i" is V[i] = C[i] | (W[i] & V[i-1]) — a carry chain, solved for all 64 lines by ONE 64-bit addition
+//   (a = W | C, b = C: carry into bit i+1 = V[i]).  Line i continues a header iff W[i] & V[i-1]; every other line starts
+//   one (or is an error: SP first, CR not followed by LF).  A header's lane stores key and value start, the lane of its
+//   last line (the next line does not continue it) stores the value end.
+// Returns false when it does not apply — no empty line inside the staged part, or more than LINE_CAP lines before it —
+// and the caller runs split_headers above.
+constexpr uint32_t LINE_CAP = ZKE_MAX_TAGBUF / 4;      // two u16 tables in the (still unused) tag buffer
+__device__ __forceinline__ bool split_headers_lines(ParseLds& L, uint32_t* ovf, const Str& raw, uint32_t& nh_out, uint32_t& perr,
+                                                    uint32_t& hdr_end) {
+#ifdef ZKE_NO_LINE_SPLIT
+  return false;
+#endif
   const uint32_t len = raw.len, staged = raw.lds_len;
-  const int lane = lane_id();
-  auto sb = [&](uint32_t pos) -> uint32_t { return __builtin_amdgcn_readfirstlane((uint32_t)L.stage[pos]); };   // pos < staged
-  uint32_t ix = 0, nh = 0;
-  uint32_t colon = NONE, vs = 0, from = 0;          // state of the header that starts at ix
+  const uint32_t lane = (uint32_t)lane_id();
+  uint16_t* lfpos = (uint16_t*)L.tagbuf;               // line g = [g ? lfpos[g-1] + 1 : 0, lfpos[g]]
+  uint16_t* colpos = lfpos + LINE_CAP;                 // its first ':' (0xFFFF: none)
   perr = 0;
-  // line-start rules of mailparse::parse_headers; 0 go on, 1 end of headers, 2 error (perr set), 3 beyond the staged bytes
-  auto line_start = [&]() -> int {
-    if (ix >= len) return 1;
-    if (ix + 1 >= staged && staged < len) return 3;
-    const uint32_t c0 = sb(ix);
-    if (c0 == '\n') return 1;
-    if (c0 == '\r') {
-      if (ix + 1 < len && sb(ix + 1) == '\n') return 1;
-      perr = ZKE_D_HDR_LONE_CR;
-      return 2;
-    }
-    if (c0 == ' ') { perr = ZKE_D_HDR_LEADING_SPACE; return 2; }
-    return 0;
-  };
-  auto put = [&](uint32_t ke, uint32_t a, uint32_t b) -> bool {
-    if (nh >= ZKE_MAX_HEADERS) { perr = ZKE_D_U_TOO_MANY_HEADERS; return false; }
-    hdr_put(L, ovf, nh, ix, ke, a, b);
-    nh++;
-    return true;
-  };
-  // value end: strip trailing CR / LF of [vs, lim)
-  auto value_end = [&](uint32_t lim) -> uint32_t {
-    uint32_t e = lim;
-    while (e > vs) { const uint32_t c = sb(e - 1); if (c != '\r' && c != '\n') break; e--; }
-    return e;
-  };
-  int st = line_start();
-  if (st == 3) return false;
-  if (st == 2) { nh_out = NONE; return true; }
-  bool done = st == 1;
-  for (uint32_t base = 0; !done && base < len; base += 64) {
-    if (staged < len && base + 64 >= staged) return false;              // the chunk and the byte after it must be staged
+  auto sb = [&](uint32_t pos) -> uint32_t { return pos < staged ? (uint32_t)L.stage[pos] : OOB; };
+  if (len == 0) { nh_out = 0; hdr_end = 0; return true; }
+  {
+    const uint32_t c0 = uni(sb(0)), c1 = uni(sb(1));
+    if (c0 == '\n' || (c0 == '\r' && c1 == '\n')) { nh_out = 0; hdr_end = 0; return true; }     // the list is empty
+  }
+  // ---- pass A
+  uint32_t n_lines = 0, cut = NONE;
+  bool colon_seen = false;                             // the line that runs into this chunk already holds a ':'
+  if (lane == 0) colpos[0] = 0xFFFF;
+  for (uint32_t base = 0; base < staged; base += 64) {
     const uint32_t l = base + lane;
-    const uint32_t c = l < len ? (uint32_t)L.stage[l] : OOB;
-    const uint32_t n = l + 1 < len ? (uint32_t)L.stage[l + 1] : OOB;
-    const uint64_t Cm = __ballot(c == ':'), Lm = __ballot(c == '\n');
-    const uint64_t Tm = __ballot(c == '\n' && n != ' ' && n != '\t');
-    for (;;) {
-      if (colon == NONE) {
-        const uint64_t m = (Cm | Lm) & bits_from(ix > base ? ix - base : 0);
-        if (!m) break;                                                    // the key runs on into the next chunk
-        const uint32_t p = base + (uint32_t)__builtin_ctzll(m);
-        if ((Lm >> (p - base)) & 1) {                                     // a line without ':' ends at its LF
-          if (!put(p, p, p)) { nh_out = NONE; return true; }
-          ix = p + 1;
-          st = line_start();
-          if (st == 3) return false;
-          if (st == 2) { nh_out = NONE; return true; }
-          if (st == 1) { done = true; break; }
-          continue;
-        }
-        colon = p;
-        vs = p + 1;
-        while (vs < len) {
-          if (vs >= staged) return false;
-          if (sb(vs) != ' ') break;
-          vs++;
-        }
-        from = p + 1;
-      }
-      const uint64_t m = Tm & bits_from(from > base ? from - base : 0);
-      if (!m) break;                                                      // the value runs on into the next chunk
-      const uint32_t q = base + (uint32_t)__builtin_ctzll(m);
-      if (!put(colon, vs, value_end(q > vs ? q : vs))) { nh_out = NONE; return true; }
-      ix = q + 1; colon = NONE;
-      st = line_start();
-      if (st == 3) return false;
-      if (st == 2) { nh_out = NONE; return true; }
-      if (st == 1) { done = true; break; }
+    const uint32_t c = sb(l), n1 = sb(l + 1), n2 = sb(l + 2);
+    uint64_t Lm = __ballot(c == '\n'), Cm = __ballot(c == ':');
+    const uint64_t Bm = __ballot(c == '\n' && (n1 == '\n' || (n1 == '\r' && n2 == '\n')));
+    uint32_t cutbit = 64;
+    if (Bm) { cutbit = (uint32_t)__builtin_ctzll(Bm); Lm &= bits_below(cutbit + 1); Cm &= bits_below(cutbit); }
+    const uint64_t below = bits_below(lane);
+    if ((Lm >> lane) & 1) {
+      const uint32_t r = n_lines + (uint32_t)__builtin_popcountll(Lm & below);
+      if (r < LINE_CAP) lfpos[r] = (uint16_t)l;
+      if (r + 1 < LINE_CAP) colpos[r + 1] = 0xFFFF;
     }
+    if ((Cm >> lane) & 1) {
+      const uint64_t lfb = Lm & below, cb = Cm & below;
+      const bool first = lfb ? (cb >> (64 - (uint32_t)__builtin_clzll(lfb))) == 0 : (cb == 0 && !colon_seen);
+      const uint32_t line = n_lines + (uint32_t)__builtin_popcountll(lfb);
+      if (first && line < LINE_CAP) colpos[line] = (uint16_t)l;
+    }
+    if (Lm) {
+      const uint32_t hl = 63u - (uint32_t)__builtin_clzll(Lm);
+      colon_seen = hl < 63 && (Cm >> (hl + 1)) != 0;
+    } else {
+      colon_seen = colon_seen || Cm != 0;
+    }
+    n_lines += (uint32_t)__builtin_popcountll(Lm);
+    if (Bm) { cut = base + cutbit; break; }
   }
-  if (!done && ix < len) {                      // the input ends inside a header: no LF closes it
-    if (colon == NONE) { if (!put(len, len, len)) { nh_out = NONE; return true; } }
-    else if (!put(colon, vs, value_end(len > vs ? len : vs))) { nh_out = NONE; return true; }
-    ix = len;
+  if (cut == NONE || n_lines > LINE_CAP) return false;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // ---- pass B
+  uint32_t nh = 0;
+  uint64_t vcarry = 0;                                 // inside a value after the previous group's last line
+  for (uint32_t G = 0; G < n_lines; G += 64) {
+    const uint32_t g = G + lane;
+    const bool valid = g < n_lines;
+    uint32_t s = 0, e = 0, c0 = OOB, c1 = OOB, col = 0xFFFF, nx = OOB;
+    if (valid) {
+      s = g ? (uint32_t)lfpos[g - 1] + 1u : 0u;
+      e = lfpos[g];
+      c0 = L.stage[s]; c1 = L.stage[s + 1];            // a line in front of the first empty one holds a byte besides its LF
+      col = colpos[g];
+      nx = L.stage[e + 1];                             // staged: pass A read it
+    }
+    const bool W = c0 == ' ' || c0 == '\t', C = col != 0xFFFF;
+    const uint64_t VM = __ballot(valid), Wm = __ballot(valid && W), Cm = __ballot(valid && C);
+    const uint64_t a = Wm | Cm, b = Cm;
+    const uint64_t Vprev = (a + b + vcarry) ^ a ^ b;   // bit i: inside a value after line i - 1
+    const uint64_t cont = Wm & Vprev;
+    const uint64_t HS = VM & ~cont;                    // lines that start a header
+    const bool hs = (HS >> lane) & 1;
+    const uint64_t below = bits_below(lane);
+    const uint32_t hr = nh + (uint32_t)__builtin_popcountll(HS & below);
+    const uint64_t bad = (HS & __ballot(valid && (c0 == ' ' || (c0 == '\r' && c1 != '\n')))) | __ballot(hs && hr >= ZKE_MAX_HEADERS);
+    if (bad) {                                         // the first one in line order, as the serial walk meets them
+      const uint32_t f = (uint32_t)__builtin_ctzll(bad);
+      const uint32_t fc = __builtin_amdgcn_readlane(c0, f);
+      // (a header-start line whose first byte is CR is not followed by LF: that would be the empty line)
+      perr = fc == ' ' ? ZKE_D_HDR_LEADING_SPACE : fc == '\r' ? ZKE_D_HDR_LONE_CR : ZKE_D_U_TOO_MANY_HEADERS;
+      nh_out = NONE;
+      return true;
+    }
+    if (hs) {
+      uint32_t ke = e, vs = e;
+      if (C) { ke = col; vs = col + 1; while (L.stage[vs] == ' ') vs++; }      // ends at the line's LF at the latest
+      uint32_t* p = hr < HDR_LDS_ENTRIES ? L.hdr + 4 * hr : ovf + 4 * (hr - HDR_LDS_ENTRIES);
+      p[0] = s; p[1] = ke; p[2] = vs;
+      if (!C) p[3] = e;                                // a line without ':' is a key with an empty value
+    }
+    const bool inval = hs ? C : true;                  // inside a value after this line
+    if (valid && inval && !(nx == ' ' || nx == '\t')) {   // the last line of a header with a value: strip trailing CR / LF
+      uint32_t q = e;
+      while (q > s) { const uint32_t t = L.stage[q - 1]; if (t != '\r' && t != '\n') break; q--; }
+      const uint32_t h = nh + (uint32_t)__builtin_popcountll(HS & bits_below(lane + 1)) - 1u;
+      uint32_t* p = h < HDR_LDS_ENTRIES ? L.hdr + 4 * h : ovf + 4 * (h - HDR_LDS_ENTRIES);
+      p[3] = q;
+    }
+    nh += (uint32_t)__builtin_popcountll(HS);
+    vcarry = ((Cm >> 63) & 1) | (((Wm >> 63) & 1) & ((Vprev >> 63) & 1));
   }
-  hdr_end = ix;
+  hdr_end = cut + 1;                                   // the empty line
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   nh_out = nh;
@@ -774,11 +832,11 @@ struct ParseArgs {
 __device__ __forceinline__ void canon_body_wave(const BatchDev& B, uint32_t i, uint32_t mode, uint32_t flags, uint32_t boff,
                                                 uint32_t blen, uint64_t len_tag, uint8_t* lds);   // debug_stop: timing experiments only (0 = off)
 
-__device__ const uint8_t DKIM_NAME[14] = {'D', 'K', 'I', 'M', '-', 'S', 'i', 'g', 'n', 'a', 't', 'u', 'r', 'e'};
 
 // The front end of e-mail i by the calling wave (L: the wave's LDS image).  parse_kernel runs it for every e-mail of a
 // batch (round 0, and mode 1); the verdict launch runs it again, round by round, for the rare e-mail whose candidate
 // signature failed while a later same-domain signature is still untried (verdict.hip.h).
+template <bool FAST = true>
 __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i, ParseLds& L) {
   const BatchDev& B = A.b;
   const int lane = lane_id();
@@ -858,7 +916,8 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
   uint32_t hdr_end = 0;
   uint32_t* hdr_ovf = (uint32_t*)(regA - HDR_OVF_BYTES);       // in front of region A
   uint32_t nh = 0;
-  if (!split_headers_staged(L, hdr_ovf, raw, nh, perr, hdr_end)) nh = split_headers(L, hdr_ovf, raw, perr, hdr_end);
+  // (the rare later rounds, inlined into the verdict launch, take the serial split: less code there)
+  if (!FAST || !split_headers_lines(L, hdr_ovf, raw, nh, perr, hdr_end)) nh = split_headers(L, hdr_ovf, raw, perr, hdr_end);
   if (nh == NONE) {
     finish(perr == ZKE_D_U_TOO_MANY_HEADERS ? ZKE_UNSUPPORTED : ZKE_PARSE_FAIL, perr);
     return;
@@ -879,11 +938,11 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
     uint32_t cvs = 0, cve = 0;
     for (uint64_t m = __ballot(hnl_lane == 12u); m; m &= m - 1) {
       const uint32_t x = (uint32_t)__builtin_ctzll(m);
-      if (span_ieq(raw, __builtin_amdgcn_readlane(hks_lane, x), 12, CT_NAME, 12)) { const HdrSpan hs = hdr_get(L, hdr_ovf, x); has_ct = true; cvs = hs.vs; cve = hs.ve; break; }
+      if (span_ieq(raw, __builtin_amdgcn_readlane(hks_lane, x), 12, LIT("content-type"))) { const HdrSpan hs = hdr_get(L, hdr_ovf, x); has_ct = true; cvs = hs.vs; cve = hs.ve; break; }
     }
     for (uint32_t x = HDR_LDS_ENTRIES; !has_ct && x < nh; x++) {
       const HdrSpan hs = hdr_get(L, hdr_ovf, x);
-      if (span_ieq(raw, hs.ks, hs.ke - hs.ks, CT_NAME, 12)) { has_ct = true; cvs = hs.vs; cve = hs.ve; }
+      if (span_ieq(raw, hs.ks, hs.ke - hs.ks, LIT("content-type"))) { has_ct = true; cvs = hs.vs; cve = hs.ve; }
     }
     if (has_ct) {
       uint32_t ixb = hdr_end;                      // behind the empty line that ended the header list
@@ -941,7 +1000,7 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
     if (hx < 64 && !((sig_len_mask >> hx) & 1)) continue;
     const HdrSpan hs = hdr_get(L, hdr_ovf, hx);
     const uint32_t ks = hs.ks, ke = hs.ke, vs = hs.vs, ve = hs.ve;
-    if (!span_ieq(raw, ks, ke - ks, DKIM_NAME, 14)) continue;
+    if (!span_ieq(raw, ks, ke - ks, LIT("dkim-signature"))) continue;
     const uint32_t this_ix = sig_ix++;
     if (first_sig_hdr == NONE) first_sig_hdr = hx;
     if (A.mode == 1 && hx != first_sig_hdr) break;
@@ -987,10 +1046,11 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
     // c=, a=, l=  (parser::parse_canonicalization, parse_hash_algo, compute_body_hash's length parse)
     uint32_t flags = 0;
     if (present & (1u << TG_C)) {
-      if (tagval_eq(L, TG_C, "simple/simple", 13) || tagval_eq(L, TG_C, "simple", 6)) flags = 0;
-      else if (tagval_eq(L, TG_C, "relaxed/simple", 14) || tagval_eq(L, TG_C, "relaxed", 7)) flags = ZKE_F_HDR_RELAXED;
-      else if (tagval_eq(L, TG_C, "simple/relaxed", 14)) flags = ZKE_F_BODY_RELAXED;
-      else if (tagval_eq(L, TG_C, "relaxed/relaxed", 15)) flags = ZKE_F_HDR_RELAXED | ZKE_F_BODY_RELAXED;
+      const TagVal c = tagval(L, TG_C);
+      if (c == LIT("relaxed/relaxed")) flags = ZKE_F_HDR_RELAXED | ZKE_F_BODY_RELAXED;
+      else if (c == LIT("relaxed/simple") || c == LIT("relaxed")) flags = ZKE_F_HDR_RELAXED;
+      else if (c == LIT("simple/simple") || c == LIT("simple")) flags = 0;
+      else if (c == LIT("simple/relaxed")) flags = ZKE_F_BODY_RELAXED;
       else {
         if (A.mode == 1) { finish(ZKE_CANON_FAIL, ZKE_D_BAD_CANON); return; }
         note_err(ZKE_D_BAD_CANON); continue;
@@ -998,9 +1058,10 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
     }
     if (A.mode == 0) {
       bool ed_alg = false;
-      if (tagval_eq(L, TG_A, "rsa-sha256", 10)) {}
-      else if (tagval_eq(L, TG_A, "rsa-sha1", 8)) flags |= ZKE_F_SHA1;
-      else if (tagval_eq(L, TG_A, "ed25519-sha256", 14)) ed_alg = true;      // RFC 8463: SHA-256 hashes, Ed25519 signature
+      const TagVal a = tagval(L, TG_A);
+      if (a == LIT("rsa-sha256")) {}
+      else if (a == LIT("rsa-sha1")) flags |= ZKE_F_SHA1;
+      else if (a == LIT("ed25519-sha256")) ed_alg = true;      // RFC 8463: SHA-256 hashes, Ed25519 signature
       else { note_err(ZKE_D_BAD_ALGO); continue; }
       // a= and the key type must name the same scheme
       if (ed_alg != (B.key_type[i] == ZKE_KEY_ED25519)) { unsupported = ZKE_D_U_ALGO_ED25519; continue; }
@@ -1134,7 +1195,9 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
         st = e + 1;
       }
     }
-    emit_header(out, mkstr(DKIM_NAME, 14), sv, hrel, false);
+    // the DKIM-Signature header itself, b= emptied, no CRLF (cfdkim uses its own spelling of the name)
+    if (hrel) { emit_lit(out, LIT("dkim-signature:")); emit_relaxed_value(out, sv); }
+    else { emit_lit(out, LIT("DKIM-Signature: ")); emit_map(out, sv, 0, sv.len, [](uint32_t c) { return c; }); }
     if (out.overflow) {
       unsupported = ZKE_D_U_PREIMAGE_OVERFLOW;
       if (A.mode == 1) { finish(ZKE_UNSUPPORTED, unsupported); return; }
@@ -1184,7 +1247,10 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
 #ifndef ZKE_PARSE_PRIO
 #define ZKE_PARSE_PRIO 0
 #endif
-__global__ __launch_bounds__(64, 6) void parse_kernel(ParseArgs A) {
+#ifndef ZKE_PARSE_WAVES
+#define ZKE_PARSE_WAVES 6        // waves per SIMD the front end is compiled for (LDS allows 23 per CU)
+#endif
+__global__ __launch_bounds__(64, ZKE_PARSE_WAVES) void parse_kernel(ParseArgs A) {
   __shared__ ParseLds L;
   if (blockIdx.x >= A.b.n) return;
   if (ZKE_PARSE_PRIO) __builtin_amdgcn_s_setprio(ZKE_PARSE_PRIO);

@@ -74,7 +74,7 @@ __device__ __forceinline__ void later_rounds(const EdVerdictArgs& A, uint32_t e,
   for (uint32_t round = A.fin.round + 1; round < A.fin.max_rounds; round++) {
     wave_publish();                                     // the verdict lane's EmailMeta / record stores
     ParseArgs pa{B, round, 0, 0, 1, nullptr, 0, nullptr, nullptr};
-    parse_email(pa, e, L);
+    parse_email<false>(pa, e, L);
     wave_publish();                                     // the front end's jobs, preimage and canonical body
     FinArgs fin = A.fin;
     fin.round = round;
