@@ -66,7 +66,7 @@ __device__ __forceinline__ void wave_publish() {
 // the same-domain signatures one after the other until one passes (behind core/src/email.rs:31-33).  Round 0 of every
 // e-mail runs in the batch's three launches; an e-mail whose round-0 candidate failed while another candidate is left is
 // rare, and giving it launches of its own would charge every batch for them: here it costs a ballot per wave.
-__device__ __forceinline__ void later_rounds(const EdVerdictArgs& A, uint32_t e, ParseLds& L) {
+__device__ __noinline__ void later_rounds(const EdVerdictArgs& A, uint32_t e, ParseLds& L) {
   const BatchDev& B = A.fin.b;
   const int lane = threadIdx.x & 63;
   EmailMeta* M = B.meta + e;
