@@ -1,11 +1,12 @@
 // ed25519.hip.h — the `k=ed25519` / `a=ed25519-sha256` branch of cfdkim's verify_signature (ed25519-dalek 2.1.1,
 // Cargo.lock:778; key bytes from helpers/src/dkim.rs:53-56,103-108), on the device.
 //
-// Mapping: ONE SIGNATURE PER LANE.  Unlike RSA (one 2048-bit Montgomery product = 64 x 64 limb products, spread
-// over a wave) a curve25519 field product is 8 x 8 limbs — too small to spread — while a batch holds thousands of
-// independent signatures, so each lane runs its own verification and the wave never diverges on data: the scalar
-// loop is bit-serial over two fixed 256-bit scalars with complete (unified) addition formulas, selections are
-// v_cndmask, and the only branches are the early-outs every lane of an all-valid wave skips together.
+// Mapping: FOUR LANES PER SIGNATURE (ed25519_verify_quad below).  Unlike RSA (one 2048-bit Montgomery product = 64 x 64
+// limb products, spread over a wave) a curve25519 field product is 8 x 8 limbs — too small to spread — so field
+// arithmetic is per lane and the four independent products of each level of the point formulas go to the four lanes
+// of a DPP quad.  The wave never diverges on data: the scalar loop is bit-serial over two fixed 256-bit scalars with
+// complete (unified) addition formulas, selections are v_cndmask, and the only branch is the early-out a wave with
+// nothing to verify takes as a whole.
 // Integer work throughout (v_mad_u64_u32); no memory traffic beyond the 32 + 64 + 32 input bytes per signature.
 //
 // Field elements: eight 32-bit limbs holding ANY 256-bit value, read modulo p = 2^255 - 19 (2^256 = 38 mod p);
@@ -398,59 +399,124 @@ ZKE_ED void sha512_ram(uint32_t out[16], const uint8_t* R, const uint8_t* A, con
   }
 }
 
-// ------------------------------------------------------------------ verification of one signature by one lane
-// returns 0 = key does not decode, 1 = key decodes but the signature is rejected, 2 = valid
-ZKE_ED uint32_t ed25519_verify_lane(const uint8_t* key, const uint8_t* msg, uint32_t mlen, const uint8_t* sig, bool have_sig) {
-  Ge A;
-  if (!ge_decompress(A, key)) return 0;
-  if (!have_sig) return 1;
+// ------------------------------------------------------------------ verification of one signature by FOUR LANES
+// A DPP quad per signature, 16 signatures per wave.  Field arithmetic stays per lane (an 8 x 8-limb product is too small
+// to spread); what is spread is the POINT arithmetic: the extended-coordinate formulas are two levels of four independent
+// products each, so lane q of the quad holds ONE coordinate (0 X, 1 Y, 2 Z, 3 T) and computes one product per level:
+//   doubling   level 1: X^2 | Y^2 | Z^2 | (X+Y)^2          level 2: E*F | G*H | F*G | E*H
+//   addition   level 1: (Y1-X1)(Y2-X2) | (Y1+X1)(Y2+X2) | T1*2dT2 | Z1*Z2     level 2: the same four
+// with quad broadcasts (8 DPP moves per field element) and a few additions between the levels.  A signature's critical
+// path is 4 products per scalar bit instead of 15, and a 1 024-signature batch is 64 waves instead of 16: the stage is
+// latency-bound (the chip holds 1 024 waves of this size), so this is what shortens it.
+//   * lane 0 decompresses A while lane 1 decompresses R (same instruction stream), each checks its point's order;
+//   * the table entries B, -A, B - A are kept as the per-lane factor of the addition's level 1
+//     (Y-X | Y+X | 2dT | Z), so a table point with any Z costs nothing extra;
+//   * compress([S]B - [k]A) == R bytes is decided without the inversion: the R bytes must be the canonical encoding of
+//     the decompressed R (y < p; the sign bit clear when x = 0 — compress never produces anything else), and then the
+//     byte strings are equal iff the points are: X = x_R Z and Y = y_R Z.
+// Same acceptance rule as above (dalek verify_strict); returns 0 = key does not decode, 1 = rejected, 2 = valid, the
+// same value in the four lanes.  Lanes of a quad pass the same pointers.
+template <int S> ZKE_ED uint32_t qb(uint32_t x) {                    // lane S of the quad to all four
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, S * 0x55 /*quad_perm:[S,S,S,S]*/, 0xf, 0xf, true);
+}
+template <int S> ZKE_ED Fe q_bcast(const Fe& a) {
+  Fe r;
+#pragma unroll
+  for (int j = 0; j < 8; j++) r.v[j] = qb<S>(a.v[j]);
+  return r;
+}
+ZKE_ED Fe q_swap23(const Fe& a) {                                    // lanes 2 and 3 exchange, 0 and 1 keep
+  Fe r;
+#pragma unroll
+  for (int j = 0; j < 8; j++) r.v[j] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.v[j], 0xB4 /*quad_perm:[0,1,3,2]*/, 0xf, 0xf, true);
+  return r;
+}
+// level 2 of both formulas: lane 0 E*F, lane 1 G*H, lane 2 F*G, lane 3 E*H
+ZKE_ED Fe q_finish(uint32_t q, const Fe& E, const Fe& F, const Fe& G, const Fe& H) {
+  const Fe o1 = fe_select(q == 1, G, fe_select(q == 2, F, E));
+  const Fe o2 = fe_select(q == 0, F, fe_select(q == 2, G, H));
+  return fe_mul(o1, o2);
+}
+ZKE_ED Fe q_dbl(const Fe& c, uint32_t q) {                           // dbl-2008-hwcd, a = -1 (ge_dbl above)
+  const Fe X = q_bcast<0>(c), Y = q_bcast<1>(c);
+  const Fe s = fe_sq(fe_select(q == 3, fe_add(X, Y), c));
+  const Fe A = q_bcast<0>(s), B = q_bcast<1>(s), ZZ = q_bcast<2>(s), S = q_bcast<3>(s);
+  const Fe Hn = fe_add(A, B);
+  const Fe G = fe_sub(B, A);
+  return q_finish(q, fe_sub(S, Hn), fe_sub(G, fe_add(ZZ, ZZ)), G, fe_neg(Hn));
+}
+ZKE_ED Fe q_add(const Fe& c, const Fe& tab, uint32_t q) {            // ge_add_cached above; tab: this lane's level-1 factor
+  const Fe X = q_bcast<0>(c), Y = q_bcast<1>(c);
+  const Fe op = fe_select(q == 0, fe_sub(Y, X), fe_select(q == 1, fe_add(Y, X), q_swap23(c)));
+  const Fe m = fe_mul(op, tab);
+  const Fe a = q_bcast<0>(m), b = q_bcast<1>(m), cc = q_bcast<2>(m), zz = q_bcast<3>(m);
+  const Fe d = fe_add(zz, zz);
+  return q_finish(q, fe_sub(b, a), fe_sub(d, cc), fe_add(d, cc), fe_add(b, a));
+}
+ZKE_ED Fe q_table(const Ge& p, uint32_t q) {                         // Y - X | Y + X | 2d T | Z
+  return fe_select(q == 0, fe_sub(p.Y, p.X), fe_select(q == 1, fe_add(p.Y, p.X), fe_select(q == 2, fe_mul(p.T, fe_2d()), p.Z)));
+}
+ZKE_ED uint32_t ed25519_verify_quad(const uint8_t* key, const uint8_t* msg, uint32_t mlen, const uint8_t* sig, bool have_sig) {
+  const uint32_t q = threadIdx.x & 3u;
+  const uint8_t* src = (q == 1) ? sig : key;
+  Ge P;                                                              // lane 0 (2, 3): A; lane 1: R
+  const bool okP = ge_decompress(P, src);
+  const bool smallP = ge_is_small_order(P);
+  // canonical encoding of this lane's point: y < p, and no sign bit on x = 0
+  const Fe yc = fe_canon(P.Y);
+  bool canonP = !(fe_is_zero(P.X) && (src[31] >> 7));
+#pragma unroll
+  for (int j = 0; j < 8; j++) canonP = canonP && yc.v[j] == P.Y.v[j];
   uint32_t S[8];
 #pragma unroll
   for (int j = 0; j < 8; j++)
     S[j] = (uint32_t)sig[32 + 4 * j] | ((uint32_t)sig[33 + 4 * j] << 8) | ((uint32_t)sig[34 + 4 * j] << 16) | ((uint32_t)sig[35 + 4 * j] << 24);
-  if (!sc_lt_L(S)) return 1;
-  Ge R;
-  if (!ge_decompress(R, sig)) return 1;
-  if (ge_is_small_order(R) || ge_is_small_order(A)) return 1;
+  const bool okA = qb<0>(okP) != 0;
+  const bool reject = !have_sig || !sc_lt_L(S) || !qb<1>(okP) || qb<0>(smallP) || qb<1>(smallP) || !qb<1>(canonP);
+  const uint32_t early = !okA ? 0u : reject ? 1u : 3u;
+  if (__ballot(early == 3u) == 0) return early;                      // nothing left to multiply in this wave
   uint32_t hw[16], k[8];
   sha512_ram(hw, sig, key, msg, mlen);
   sc_reduce512(k, hw);
+  const Fe Ax = q_bcast<0>(P.X), Ay = q_bcast<0>(P.Y), At = q_bcast<0>(P.T);
+  const Fe Rx = q_bcast<1>(P.X), Ry = q_bcast<1>(P.Y);
   // base point: y = 4/5, the even x
   const Fe by = Fe{{0x66666658u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u}};
   const Fe bx = Fe{{0x8f25d51au, 0xc9562d60u, 0x9525a7b2u, 0x692cc760u, 0xfdd6dc5cu, 0xc0a4e231u, 0xcd6e53feu, 0x216936d3u}};
   const Ge B = Ge{bx, by, fe_small(1), fe_mul(bx, by)};
-  const Ge nA = ge_neg(A);
-  const Ge BnA = ge_add(B, nA);
-  const Fe B_t2d = fe_mul(B.T, fe_2d()), nA_t2d = fe_mul(nA.T, fe_2d()), BnA_t2d = fe_mul(BnA.T, fe_2d());
-  Ge acc = ge_identity();
+  const Ge nA = Ge{fe_neg(Ax), Ay, fe_small(1), fe_neg(At)};
+  const Fe tB = q_table(B, q), tnA = q_table(nA, q), tBnA = q_table(ge_add(B, nA), q);
+  const Fe tId = fe_small(q == 2 ? 0u : 1u);
+  Fe c = fe_small((q == 1 || q == 2) ? 1u : 0u);                     // the identity (0 : 1 : 1 : 0)
 #pragma unroll 1
   for (int bit = 0; bit < 256; bit++) {
-    acc = ge_dbl(acc);
+    c = q_dbl(c, q);
     const bool sb = (S[7] >> 31) != 0, kb = (k[7] >> 31) != 0;      // most significant bit first; both scalars shift left
 #pragma unroll
     for (int j = 7; j > 0; j--) { S[j] = (S[j] << 1) | (S[j - 1] >> 31); k[j] = (k[j] << 1) | (k[j - 1] >> 31); }
     S[0] <<= 1; k[0] <<= 1;
-    Ge t = ge_select(sb, B, ge_identity());
-    t = ge_select(kb, ge_select(sb, BnA, nA), t);
-    Fe t2d = fe_select(sb, B_t2d, fe_small(0));
-    t2d = fe_select(kb, fe_select(sb, BnA_t2d, nA_t2d), t2d);
-    acc = ge_add_cached(acc, t, t2d);
+    c = q_add(c, fe_select(kb, fe_select(sb, tBnA, tnA), fe_select(sb, tB, tId)), q);
   }
-  uint32_t enc[8];
-  ge_compress(enc, acc);
-  bool same = true;
-#pragma unroll
-  for (int j = 0; j < 8; j++)
-    same = same && enc[j] == ((uint32_t)sig[4 * j] | ((uint32_t)sig[4 * j + 1] << 8) | ((uint32_t)sig[4 * j + 2] << 16) | ((uint32_t)sig[4 * j + 3] << 24));
-  return same ? 2u : 1u;
+  const Fe Z = q_bcast<2>(c);
+  const bool eq = fe_eq(fe_mul(fe_select(q == 0, Rx, Ry), Z), c);   // lane 0: x_R Z == X, lane 1: y_R Z == Y
+  const bool same = qb<0>(eq) != 0 && qb<1>(eq) != 0;
+  return early == 3u ? (same ? 2u : 1u) : early;
 }
 
-// building-block kernel: n independent (key, message, signature) triples, 32-byte messages, packed arrays
+// the same as a real call, for the rare caller (later signature rounds) that should not carry a second inlined copy
+__device__ __noinline__ uint32_t ed25519_verify_quad_call(const uint8_t* key, const uint8_t* msg, uint32_t mlen,
+                                                                                                const uint8_t* sig, bool have_sig) {
+  return ed25519_verify_quad(key, msg, mlen, sig, have_sig);
+}
+
+// building-block kernel: n independent (key, message, signature) triples, 32-byte messages, packed arrays; 16 per wave
 __global__ __launch_bounds__(64) void ed25519_verify_kernel(const uint8_t* keys, const uint8_t* msgs, uint32_t msg_len,
                                                             const uint8_t* sigs, uint32_t n, uint32_t* out) {
-  const uint32_t i = blockIdx.x * 64 + threadIdx.x;
-  if (i >= n) return;
-  out[i] = ed25519_verify_lane(keys + (size_t)i * 32, msgs + (size_t)i * msg_len, msg_len, sigs + (size_t)i * 64, true);
+  uint32_t i = blockIdx.x * 16 + (threadIdx.x >> 2);
+  const bool live = i < n;
+  if (!live) i = n - 1;                                              // whole quads stay in step; the result is dropped
+  const uint32_t r = ed25519_verify_quad(keys + (size_t)i * 32, msgs + (size_t)i * msg_len, msg_len, sigs + (size_t)i * 64, true);
+  if (live && (threadIdx.x & 3) == 0) out[i] = r;
 }
 
 }  // namespace zke

@@ -538,7 +538,7 @@ int zke_ed25519_verify_batch(zke_engine* e, const uint8_t* keys, const uint8_t* 
   if (he == hipSuccess) he = hipMemcpyAsync(dm.p, msgs, (size_t)n * msg_len, hipMemcpyHostToDevice, e->stream);
   if (he == hipSuccess) he = hipMemcpyAsync(ds.p, sigs, (size_t)n * 64, hipMemcpyHostToDevice, e->stream);
   if (he == hipSuccess) {
-    hipLaunchKernelGGL(ed25519_verify_kernel, dim3((n + 63) / 64), dim3(64), 0, e->stream, dk.as<uint8_t>(), dm.as<uint8_t>(), msg_len,
+    hipLaunchKernelGGL(ed25519_verify_kernel, dim3((n + 15) / 16), dim3(64), 0, e->stream, dk.as<uint8_t>(), dm.as<uint8_t>(), msg_len,
                        ds.as<uint8_t>(), n, dout.as<uint32_t>());
     he = hipGetLastError();
   }

@@ -135,7 +135,7 @@ __device__ __forceinline__ Str mkstr(const uint8_t* b, uint32_t len) { return St
 // s[a, b) as a string of its own (keeps the LDS window)
 __device__ __forceinline__ Str substr(const Str& s, uint32_t a, uint32_t b) {
   Str r{s.base + a, b - a, NONE, 0, nullptr, 0};
-  if (s.lds && a < s.lds_len) { r.lds = s.lds + a; r.lds_len = s.lds_len - a; }
+  if (a < s.lds_len) { r.lds = s.lds + a; r.lds_len = s.lds_len - a; }
   return r;
 }
 __device__ __forceinline__ uint32_t ldb(const Str& s, uint32_t l) {

@@ -115,7 +115,7 @@ int run_device_pipeline(zke_engine* e, Slot& w, const zke_batch* in, uint64_t ra
     // Ed25519 stage + verdicts (verdict.hip.h): bh compare, EM digest against the header hash, status / detail, pending counter
     EdVerdictArgs va{FinArgs{B, round, rounds, w.pending.as<uint32_t>(), e->debug_skip_rsa}, e->debug_skip_ed, wave_count,
                      e->key_cache.as<KeyCacheEntry>(), want_em ? w.em_dbg.as<uint8_t>() : nullptr};
-    if (!(x_skip & 2)) hipLaunchKernelGGL(ed_verdict_kernel, dim3((n + 63) / 64), dim3(64), 0, s, va);
+    if (!(x_skip & 2)) hipLaunchKernelGGL(ed_verdict_kernel, dim3((n + VERDICT_EMAILS_PER_WAVE - 1) / VERDICT_EMAILS_PER_WAVE), dim3(64), 0, s, va);
     tm.mark(); tm.mark();      // sha_us = the hash / modexp launch, rsa_us = the Ed25519 + verdict launch (finalize_us reads 0)
   }
   HIPCHK(e, hipGetLastError());

@@ -1,9 +1,9 @@
 // verdict.hip.h — the last launch of a signature round: the Ed25519 stage and the verdict of every e-mail.
 //
-// One wave per 64 e-mails.  First, lane per e-mail, what ed25519_email_kernel did as a launch of its own: the curve-point
-// check of every 32-byte Ed25519 key (round 0; DkimPublicKey::try_from_bytes, core/src/email.rs:28-29) and the Ed25519
-// verification of a=ed25519-sha256 candidates over the SHA-256 header hash — waves without an Ed25519 e-mail skip it after
-// one byte load per lane.  Then every lane writes its e-mail's verdict (verdict_lane, canon.hip.h): base64(body hash)
+// One wave per 16 e-mails.  First, four lanes per e-mail (ed25519.hip.h), what ed25519_email_kernel did as a launch of its
+// own: the curve-point check of every 32-byte Ed25519 key (round 0; DkimPublicKey::try_from_bytes, core/src/email.rs:28-29)
+// and the Ed25519 verification of a=ed25519-sha256 candidates over the SHA-256 header hash — waves without an Ed25519 e-mail
+// skip it after one byte load per lane.  Then a lane per e-mail writes the verdict (verdict_lane, canon.hip.h): base64(body hash)
 // against bh=, the digest bytes the RSA role left in EmailMeta against the header hash (rsa 0.9.6 pkcs1v15 verify),
 // status / detail, the pending counter of the next signature round.  One launch instead of two: with many batches in
 // flight every launch of a batch costs the chip's command processor several microseconds whatever it does.
@@ -66,7 +66,7 @@ __device__ __forceinline__ void wave_publish() {
 // the same-domain signatures one after the other until one passes (behind core/src/email.rs:31-33).  Round 0 of every
 // e-mail runs in the batch's three launches; an e-mail whose round-0 candidate failed while another candidate is left is
 // rare, and giving it launches of its own would charge every batch for them: here it costs a ballot per wave.
-__device__ __noinline__ void later_rounds(const EdVerdictArgs& A, uint32_t e, ParseLds& L) {
+__device__ __forceinline__ void later_rounds(const EdVerdictArgs& A, uint32_t e, ParseLds& L) {
   const BatchDev& B = A.fin.b;
   const int lane = threadIdx.x & 63;
   EmailMeta* M = B.meta + e;
@@ -83,12 +83,9 @@ __device__ __noinline__ void later_rounds(const EdVerdictArgs& A, uint32_t e, Pa
       if (lane < 2) sha_lane(B.sha[(size_t)lane * B.n_pad + e]);      // kind 0: body, kind 1: header preimage
       wave_publish();
       if (M->flags & ZKE_F_ED25519) {
-        uint32_t r = 0;
-        if (lane == 0) {
-          const RsaJob* J = B.rsa + e;
-          r = ed25519_verify_lane(B.key + B.key_off[e], R->header_hash, 32, J->sig + (512 - 64), J->sig_len == 64);
-          M->ed_ok = (r == 2) ? 1u : 0u;
-        }
+        const RsaJob* J = B.rsa + e;                        // (every quad of the wave verifies this one signature)
+        const uint32_t r = ed25519_verify_quad_call(B.key + B.key_off[e], R->header_hash, 32, J->sig + (512 - 64), J->sig_len == 64);
+        if (lane == 0) M->ed_ok = (r == 2) ? 1u : 0u;
         ed_ok = __builtin_amdgcn_readfirstlane(r) == 2;
       } else {
         rsa_ok = rsa_wave_any(B.rsa, e, reinterpret_cast<const uint8_t*>(B.results) + offsetof(zke_result, header_hash), sizeof(zke_result),
@@ -102,36 +99,57 @@ __device__ __noinline__ void later_rounds(const EdVerdictArgs& A, uint32_t e, Pa
 }
 
 #ifndef ZKE_VERDICT_WAVES
-#define ZKE_VERDICT_WAVES 1      // waves per SIMD the verdict launch is compiled for (1: 256 VGPRs, no spills)
+#define ZKE_VERDICT_WAVES 1      // waves per SIMD the verdict launch is compiled for
 #endif
+constexpr uint32_t VERDICT_EMAILS_PER_WAVE = 16;      // a DPP quad per e-mail in the Ed25519 stage
 __global__ __launch_bounds__(64, ZKE_VERDICT_WAVES) void ed_verdict_kernel(EdVerdictArgs A) {
   __shared__ ParseLds L;
   const BatchDev& B = A.fin.b;
   const int lane = threadIdx.x & 63;
-  const uint32_t base = blockIdx.x * 64, i = base + (uint32_t)lane;
+  const uint32_t base = blockIdx.x * VERDICT_EMAILS_PER_WAVE;
   if (blockIdx.x == 0 && lane == 0 && A.wave_count) *A.wave_count = 0;
-  // ---- Ed25519 stage, lane per e-mail; results stay in registers (ed_ok, ed_bad) and go to EmailMeta for later rounds
-  uint32_t ed_ok = 0, ed_bad = 0;
-  if (i < B.n) {
-    EmailMeta* M = B.meta + i;
-    ed_bad = M->ed_key_bad;                          // decided in round 0
-    if (!A.skip_ed && B.key_type[i] == ZKE_KEY_ED25519 && M->key_ok == 2) {
-      const bool cand = M->state == ST_CAND && (M->flags & ZKE_F_ED25519);
-      if (A.fin.round == 0 || cand) {                // the key itself is checked in round 0
-        const RsaJob* J = B.rsa + i;
-        const zke_result* R = B.results + i;
-        const bool have_sig = cand && J->sig_len == 64;  // a b= of any other length cannot be an Ed25519 signature
-        const uint32_t r = ed25519_verify_lane(B.key + B.key_off[i], R->header_hash, 32, J->sig + (512 - 64), have_sig);
-        if (r == 0) { ed_bad = 1; M->ed_key_bad = 1; }
-        ed_ok = (r == 2) ? 1u : 0u;
-        M->ed_ok = ed_ok;
+  // ---- Ed25519 stage, four lanes per e-mail (quad j = e-mail base + j): the curve-point check of every 32-byte key in
+  // round 0, the verification of a=ed25519-sha256 candidates over the SHA-256 header hash.  Results reach EmailMeta (later
+  // rounds) and, below, the e-mail's verdict lane.
+  uint32_t ed_res = 3;                                  // 3 = this e-mail has no Ed25519 work in this round
+  {
+    const uint32_t i = base + ((uint32_t)lane >> 2);
+    bool work = false, have_sig = false;
+    // (quads without work run along on bytes that are always there: the start of the result records)
+    const uint8_t* key = reinterpret_cast<const uint8_t*>(B.results);
+    const uint8_t* msg = key;
+    const uint8_t* sig = key;
+    if (i < B.n) {
+      const EmailMeta* M = B.meta + i;
+      if (!A.skip_ed && B.key_type[i] == ZKE_KEY_ED25519 && M->key_ok == 2) {
+        const bool cand = M->state == ST_CAND && (M->flags & ZKE_F_ED25519);
+        if (A.fin.round == 0 || cand) {               // the key itself is checked in round 0
+          const RsaJob* J = B.rsa + i;
+          work = true;
+          have_sig = cand && J->sig_len == 64;        // a b= of any other length cannot be an Ed25519 signature
+          key = B.key + B.key_off[i]; msg = B.results[i].header_hash; sig = J->sig + (512 - 64);
+        }
+      }
+    }
+    if (__ballot(work)) {
+      const uint32_t r = ed25519_verify_quad(key, msg, 32, sig, have_sig);
+      if (work) {
+        ed_res = r;
+        if ((lane & 3) == 0) {
+          EmailMeta* M = B.meta + i;
+          if (r == 0) M->ed_key_bad = 1;
+          M->ed_ok = (r == 2) ? 1u : 0u;
+        }
       }
     }
   }
-  // ---- verdicts, lane per e-mail
+  // ---- verdicts, lane per e-mail (lanes 0..15); e-mail j's Ed25519 result sits in lanes 4j..4j+3
+  const uint32_t mine = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(16u * ((uint32_t)lane & 15u)), (int)ed_res);
+  const uint32_t i = base + (uint32_t)lane;
   bool again = false;
-  if (i < B.n) {
+  if (lane < (int)VERDICT_EMAILS_PER_WAVE && i < B.n) {
     const EmailMeta* M = B.meta + i;
+    const bool ed_bad = (mine == 0) || (mine == 3 && M->ed_key_bad != 0);      // decided in round 0
     bool rsa_ok = false;
     if (M->state == ST_CAND && !(M->flags & ZKE_F_ED25519) && M->em_ok) {
       // rsa 0.9.6 pkcs1v15 verify, last step: EM's trailing digest (little-endian limbs) against the header hash as stored
@@ -140,7 +158,7 @@ __global__ __launch_bounds__(64, ZKE_VERDICT_WAVES) void ed_verdict_kernel(EdVer
       rsa_ok = true;
       for (uint32_t l = 0; l < hl4; l++) rsa_ok = rsa_ok && M->em_tail[l] == __builtin_bswap32(hw[hl4 - 1 - l]);
     }
-    again = verdict_lane(A.fin, i, rsa_ok, ed_ok != 0, ed_bad != 0);
+    again = verdict_lane(A.fin, i, rsa_ok, mine == 2, ed_bad);
   }
   // ---- later signature rounds of the e-mails that are still undecided, one at a time with the whole wave
   for (uint64_t pend = __ballot(again); pend; pend &= pend - 1) later_rounds(A, base + (uint32_t)__builtin_ctzll(pend), L);
