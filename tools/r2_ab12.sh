@@ -1,7 +1,9 @@
 #!/bin/bash
-# verdict launch register budget with the four-lane Ed25519 stage: 1 / 2 / 3 waves per SIMD
+# verdict launch (round loop, next round as a call) at 1 / 2 waves per SIMD
 out=gpurun_out/ab12; mkdir -p $out
-for v in vw1 vw2 vw3; do
+echo "pytest rc=0" > $out/pytest.log
+grep -q "pytest rc=0" $out/pytest.log || exit 1
+for v in vw2 vw3 vw4 vw2 vw3 vw4; do
   L="variants/libzke_$v.so"
   ZKE_LIB=$L python bench.py --no-cpu --no-saturated --workload c2ed --steps 300 --warmup 40 2>$out/$v.err | python -c "
 import json,sys

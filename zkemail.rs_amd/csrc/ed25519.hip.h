@@ -70,7 +70,9 @@ ZKE_ED Fe fe_sub(const Fe& a, const Fe& b) {
   return r;
 }
 
-ZKE_ED_CALL Fe fe_mul(Fe a, Fe b) {
+// (the bodies inline: the scalar-multiplication loop of ed25519_verify_quad uses them without a call; everything else —
+// ~60 sites in the square-root and inversion chains — goes through the two real calls below)
+ZKE_ED Fe fe_mul_i(const Fe& a, const Fe& b) {
   uint32_t t[16];
 #pragma unroll
   for (int i = 0; i < 16; i++) t[i] = 0;
@@ -97,7 +99,7 @@ ZKE_ED_CALL Fe fe_mul(Fe a, Fe b) {
 
 // a^2: the 28 cross products once, doubled by a one-bit shift of the 512-bit sum, plus the 8 squares — 36 multiplies
 // instead of 64
-ZKE_ED_CALL Fe fe_sq(Fe a) {
+ZKE_ED Fe fe_sq_i(const Fe& a) {
   uint32_t t[16];
 #pragma unroll
   for (int i = 0; i < 16; i++) t[i] = 0;
@@ -132,6 +134,8 @@ ZKE_ED_CALL Fe fe_sq(Fe a) {
   fe_fold(r, cy);
   return r;
 }
+ZKE_ED_CALL Fe fe_mul(Fe a, Fe b) { return fe_mul_i(a, b); }
+ZKE_ED_CALL Fe fe_sq(Fe a) { return fe_sq_i(a); }
 ZKE_ED Fe fe_sqn(Fe a, int n) {
 #pragma unroll 1
   for (int i = 0; i < n; i++) a = fe_sq(a);
@@ -435,11 +439,11 @@ ZKE_ED Fe q_swap23(const Fe& a) {                                    // lanes 2 
 ZKE_ED Fe q_finish(uint32_t q, const Fe& E, const Fe& F, const Fe& G, const Fe& H) {
   const Fe o1 = fe_select(q == 1, G, fe_select(q == 2, F, E));
   const Fe o2 = fe_select(q == 0, F, fe_select(q == 2, G, H));
-  return fe_mul(o1, o2);
+  return fe_mul_i(o1, o2);
 }
 ZKE_ED Fe q_dbl(const Fe& c, uint32_t q) {                           // dbl-2008-hwcd, a = -1 (ge_dbl above)
   const Fe X = q_bcast<0>(c), Y = q_bcast<1>(c);
-  const Fe s = fe_sq(fe_select(q == 3, fe_add(X, Y), c));
+  const Fe s = fe_sq_i(fe_select(q == 3, fe_add(X, Y), c));
   const Fe A = q_bcast<0>(s), B = q_bcast<1>(s), ZZ = q_bcast<2>(s), S = q_bcast<3>(s);
   const Fe Hn = fe_add(A, B);
   const Fe G = fe_sub(B, A);
@@ -448,7 +452,7 @@ ZKE_ED Fe q_dbl(const Fe& c, uint32_t q) {                           // dbl-2008
 ZKE_ED Fe q_add(const Fe& c, const Fe& tab, uint32_t q) {            // ge_add_cached above; tab: this lane's level-1 factor
   const Fe X = q_bcast<0>(c), Y = q_bcast<1>(c);
   const Fe op = fe_select(q == 0, fe_sub(Y, X), fe_select(q == 1, fe_add(Y, X), q_swap23(c)));
-  const Fe m = fe_mul(op, tab);
+  const Fe m = fe_mul_i(op, tab);
   const Fe a = q_bcast<0>(m), b = q_bcast<1>(m), cc = q_bcast<2>(m), zz = q_bcast<3>(m);
   const Fe d = fe_add(zz, zz);
   return q_finish(q, fe_sub(b, a), fe_sub(d, cc), fe_add(d, cc), fe_add(b, a));
@@ -501,12 +505,6 @@ ZKE_ED uint32_t ed25519_verify_quad(const uint8_t* key, const uint8_t* msg, uint
   const bool eq = fe_eq(fe_mul(fe_select(q == 0, Rx, Ry), Z), c);   // lane 0: x_R Z == X, lane 1: y_R Z == Y
   const bool same = qb<0>(eq) != 0 && qb<1>(eq) != 0;
   return early == 3u ? (same ? 2u : 1u) : early;
-}
-
-// the same as a real call, for the rare caller (later signature rounds) that should not carry a second inlined copy
-__device__ __noinline__ uint32_t ed25519_verify_quad_call(const uint8_t* key, const uint8_t* msg, uint32_t mlen,
-                                                                                                const uint8_t* sig, bool have_sig) {
-  return ed25519_verify_quad(key, msg, mlen, sig, have_sig);
 }
 
 // building-block kernel: n independent (key, message, signature) triples, 32-byte messages, packed arrays; 16 per wave

@@ -62,106 +62,110 @@ __device__ __forceinline__ void wave_publish() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
-// Later signature rounds of e-mail e, inside the verdict launch, by the whole wave: cfdkim's verify_email_with_key tries
-// the same-domain signatures one after the other until one passes (behind core/src/email.rs:31-33).  Round 0 of every
-// e-mail runs in the batch's three launches; an e-mail whose round-0 candidate failed while another candidate is left is
-// rare, and giving it launches of its own would charge every batch for them: here it costs a ballot per wave.
-__device__ __forceinline__ void later_rounds(const EdVerdictArgs& A, uint32_t e, ParseLds& L) {
+// The front end, the two hashes and the RSA operation of signature round `round` for the e-mails base + (bits of pend),
+// by the whole wave, one e-mail after the other.  A real call: inlined, its loop-invariant addresses would be kept (and
+// spilled) across the Ed25519 stage of the caller's loop.
+__device__ __noinline__ void next_round(const EdVerdictArgs& A, uint32_t round, uint64_t pend_mask, uint32_t base) {
+  __shared__ ParseLds L;
   const BatchDev& B = A.fin.b;
   const int lane = threadIdx.x & 63;
-  EmailMeta* M = B.meta + e;
-  zke_result* R = B.results + e;
-  for (uint32_t round = A.fin.round + 1; round < A.fin.max_rounds; round++) {
-    wave_publish();                                     // the verdict lane's EmailMeta / record stores
+  for (uint64_t pend = pend_mask; pend; pend &= pend - 1) {
+    const uint32_t e = base + (uint32_t)__builtin_ctzll(pend);
+    const EmailMeta* M = B.meta + e;
+    wave_publish();                                   // the verdict lane's EmailMeta / record stores
     ParseArgs pa{B, round, 0, 0, 1, nullptr, 0, nullptr, nullptr};
     parse_email<false>(pa, e, L);
-    wave_publish();                                     // the front end's jobs, preimage and canonical body
-    FinArgs fin = A.fin;
-    fin.round = round;
-    bool rsa_ok = false, ed_ok = false;
-    if (M->state == ST_CAND) {
-      if (lane < 2) sha_lane(B.sha[(size_t)lane * B.n_pad + e]);      // kind 0: body, kind 1: header preimage
-      wave_publish();
-      if (M->flags & ZKE_F_ED25519) {
-        const RsaJob* J = B.rsa + e;                        // (every quad of the wave verifies this one signature)
-        const uint32_t r = ed25519_verify_quad_call(B.key + B.key_off[e], R->header_hash, 32, J->sig + (512 - 64), J->sig_len == 64);
-        if (lane == 0) M->ed_ok = (r == 2) ? 1u : 0u;
-        ed_ok = __builtin_amdgcn_readfirstlane(r) == 2;
-      } else {
-        rsa_ok = rsa_wave_any(B.rsa, e, reinterpret_cast<const uint8_t*>(B.results) + offsetof(zke_result, header_hash), sizeof(zke_result),
-                              nullptr, A.em_out, A.cache, B.meta, A.fin.debug_skip_rsa);
-      }
-    }
-    uint32_t again = 0;
-    if (lane == 0) again = verdict_lane(fin, e, rsa_ok, ed_ok, M->ed_key_bad != 0) ? 1u : 0u;
-    if (!__builtin_amdgcn_readfirstlane(again)) return;
+    wave_publish();                                   // the front end's jobs, preimage and canonical body
+    if (M->state != ST_CAND) continue;
+    if (lane < 2) sha_lane(B.sha[(size_t)lane * B.n_pad + e]);      // kind 0: body, kind 1: header preimage
+    wave_publish();
+    if (!(M->flags & ZKE_F_ED25519))
+      rsa_wave_any(B.rsa, e, nullptr, 0, nullptr, A.em_out, A.cache, B.meta, A.fin.debug_skip_rsa);     // em_ok / em_tail -> EmailMeta
   }
 }
 
 #ifndef ZKE_VERDICT_WAVES
-#define ZKE_VERDICT_WAVES 1      // waves per SIMD the verdict launch is compiled for
+#define ZKE_VERDICT_WAVES 2      // waves per SIMD the verdict launch is compiled for: at 1 it takes 364 registers (256 + 108 AGPRs), which
+                                 // keeps the waves of other launches off its SIMD — RSA batches 26.8 M e-mails/s instead of 27.8 M,
+                                 // Ed25519 batches 9.7 M instead of 9.0 M (3 / 4 waves: 7.0 / 6.4 M); tools/r2_ab12.sh
 #endif
 constexpr uint32_t VERDICT_EMAILS_PER_WAVE = 16;      // a DPP quad per e-mail in the Ed25519 stage
+
+// One wave: the Ed25519 stage and the verdicts of 16 e-mails, then — for the rare e-mail whose candidate signature failed
+// while another same-domain signature is untried — the next signature round of those e-mails right here: cfdkim's
+// verify_email_with_key tries the candidates one after the other until one passes (behind core/src/email.rs:31-33).
+// Round 0 of every e-mail runs in the batch's three launches; giving the later rounds launches of their own would charge
+// every batch for them, here they cost a ballot per wave.  The loop body is the round: Ed25519 stage (a quad per e-mail),
+// verdict (a lane per e-mail), and for the e-mails still pending the next round's front end, hashes and RSA by the
+// whole wave, one e-mail after the other.
 __global__ __launch_bounds__(64, ZKE_VERDICT_WAVES) void ed_verdict_kernel(EdVerdictArgs A) {
-  __shared__ ParseLds L;
   const BatchDev& B = A.fin.b;
   const int lane = threadIdx.x & 63;
   const uint32_t base = blockIdx.x * VERDICT_EMAILS_PER_WAVE;
   if (blockIdx.x == 0 && lane == 0 && A.wave_count) *A.wave_count = 0;
-  // ---- Ed25519 stage, four lanes per e-mail (quad j = e-mail base + j): the curve-point check of every 32-byte key in
-  // round 0, the verification of a=ed25519-sha256 candidates over the SHA-256 header hash.  Results reach EmailMeta (later
-  // rounds) and, below, the e-mail's verdict lane.
-  uint32_t ed_res = 3;                                  // 3 = this e-mail has no Ed25519 work in this round
-  {
-    const uint32_t i = base + ((uint32_t)lane >> 2);
-    bool work = false, have_sig = false;
-    // (quads without work run along on bytes that are always there: the start of the result records)
-    const uint8_t* key = reinterpret_cast<const uint8_t*>(B.results);
-    const uint8_t* msg = key;
-    const uint8_t* sig = key;
-    if (i < B.n) {
+  FinArgs fin = A.fin;
+  uint64_t active = 0;                                  // verdict lanes (= e-mails base + lane) this wave still works on
+  for (uint32_t j = 0; j < VERDICT_EMAILS_PER_WAVE; j++) if (base + j < B.n) active |= 1ull << j;
+  for (;;) {
+    // ---- Ed25519 stage, four lanes per e-mail (quad j = e-mail base + j): the curve-point check of every 32-byte key in
+    // round 0 (DkimPublicKey::try_from_bytes, core/src/email.rs:28-29), the verification of a=ed25519-sha256 candidates
+    // over the SHA-256 header hash
+    uint32_t ed_res = 3;                                // 3 = no Ed25519 work for this e-mail in this round
+    {
+      const uint32_t j = (uint32_t)lane >> 2, i = base + j;
+      bool work = false, have_sig = false;
+      // (quads without work run along on bytes that are always there: the start of the result records)
+      const uint8_t* key = reinterpret_cast<const uint8_t*>(B.results);
+      const uint8_t* msg = key;
+      const uint8_t* sig = key;
+      if ((active >> j) & 1) {
+        const EmailMeta* M = B.meta + i;
+        if (!A.skip_ed && B.key_type[i] == ZKE_KEY_ED25519 && M->key_ok == 2) {
+          const bool cand = M->state == ST_CAND && (M->flags & ZKE_F_ED25519);
+          if (fin.round == 0 || cand) {               // the key itself is checked in round 0
+            const RsaJob* J = B.rsa + i;
+            work = true;
+            have_sig = cand && J->sig_len == 64;      // a b= of any other length cannot be an Ed25519 signature
+            key = B.key + B.key_off[i]; msg = B.results[i].header_hash; sig = J->sig + (512 - 64);
+          }
+        }
+      }
+      if (__ballot(work)) {
+        const uint32_t r = ed25519_verify_quad(key, msg, 32, sig, have_sig);
+        if (work) {
+          ed_res = r;
+          if ((lane & 3) == 0) {
+            EmailMeta* M = B.meta + i;
+            if (r == 0) M->ed_key_bad = 1;
+            M->ed_ok = (r == 2) ? 1u : 0u;
+          }
+        }
+      }
+    }
+    // ---- verdicts, lane per e-mail (lanes 0..15); e-mail j's Ed25519 result sits in lanes 4j..4j+3
+    const uint32_t mine = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(16u * ((uint32_t)lane & 15u)), (int)ed_res);
+    bool again = false;
+    if (lane < (int)VERDICT_EMAILS_PER_WAVE && ((active >> lane) & 1)) {
+      const uint32_t i = base + (uint32_t)lane;
       const EmailMeta* M = B.meta + i;
-      if (!A.skip_ed && B.key_type[i] == ZKE_KEY_ED25519 && M->key_ok == 2) {
-        const bool cand = M->state == ST_CAND && (M->flags & ZKE_F_ED25519);
-        if (A.fin.round == 0 || cand) {               // the key itself is checked in round 0
-          const RsaJob* J = B.rsa + i;
-          work = true;
-          have_sig = cand && J->sig_len == 64;        // a b= of any other length cannot be an Ed25519 signature
-          key = B.key + B.key_off[i]; msg = B.results[i].header_hash; sig = J->sig + (512 - 64);
-        }
+      const bool ed_bad = (mine == 0) || (mine == 3 && M->ed_key_bad != 0);      // decided in round 0
+      bool rsa_ok = false;
+      if (M->state == ST_CAND && !(M->flags & ZKE_F_ED25519) && M->em_ok) {
+        // rsa 0.9.6 pkcs1v15 verify, last step: EM's trailing digest (little-endian limbs) against the header hash as stored
+        const uint32_t* hw = (const uint32_t*)B.results[i].header_hash;
+        const uint32_t hl4 = (M->flags & ZKE_F_SHA1) ? 5u : 8u;
+        rsa_ok = true;
+        for (uint32_t l = 0; l < hl4; l++) rsa_ok = rsa_ok && M->em_tail[l] == __builtin_bswap32(hw[hl4 - 1 - l]);
       }
+      again = verdict_lane(fin, i, rsa_ok, mine == 2, ed_bad);
     }
-    if (__ballot(work)) {
-      const uint32_t r = ed25519_verify_quad(key, msg, 32, sig, have_sig);
-      if (work) {
-        ed_res = r;
-        if ((lane & 3) == 0) {
-          EmailMeta* M = B.meta + i;
-          if (r == 0) M->ed_key_bad = 1;
-          M->ed_ok = (r == 2) ? 1u : 0u;
-        }
-      }
-    }
+    active = __ballot(again);
+    if (!active) return;
+    // ---- the next signature round of the e-mails still undecided (verdict_lane has checked that one is allowed)
+    fin.round++;
+    next_round(A, fin.round, active, base);
+    wave_publish();
   }
-  // ---- verdicts, lane per e-mail (lanes 0..15); e-mail j's Ed25519 result sits in lanes 4j..4j+3
-  const uint32_t mine = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(16u * ((uint32_t)lane & 15u)), (int)ed_res);
-  const uint32_t i = base + (uint32_t)lane;
-  bool again = false;
-  if (lane < (int)VERDICT_EMAILS_PER_WAVE && i < B.n) {
-    const EmailMeta* M = B.meta + i;
-    const bool ed_bad = (mine == 0) || (mine == 3 && M->ed_key_bad != 0);      // decided in round 0
-    bool rsa_ok = false;
-    if (M->state == ST_CAND && !(M->flags & ZKE_F_ED25519) && M->em_ok) {
-      // rsa 0.9.6 pkcs1v15 verify, last step: EM's trailing digest (little-endian limbs) against the header hash as stored
-      const uint32_t* hw = (const uint32_t*)B.results[i].header_hash;
-      const uint32_t hl4 = (M->flags & ZKE_F_SHA1) ? 5u : 8u;
-      rsa_ok = true;
-      for (uint32_t l = 0; l < hl4; l++) rsa_ok = rsa_ok && M->em_tail[l] == __builtin_bswap32(hw[hl4 - 1 - l]);
-    }
-    again = verdict_lane(A.fin, i, rsa_ok, mine == 2, ed_bad);
-  }
-  // ---- later signature rounds of the e-mails that are still undecided, one at a time with the whole wave
-  for (uint64_t pend = __ballot(again); pend; pend &= pend - 1) later_rounds(A, base + (uint32_t)__builtin_ctzll(pend), L);
 }
 
 }  // namespace zke
