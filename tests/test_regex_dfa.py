@@ -15,11 +15,14 @@ PATTERNS = [
     r"\d+", r"\w+@\w+\.com", r"\s+", r"[\d\-]+", r"[a\]]+", r"a\.b", r"from:[^\r\n]*@example\.com", r"\r\n",
     r"subject:[^\r\n]+\r\n", r"a??b", r"a+?", r"(a+)(b+)", r"[A-Za-z0-9._%+-]+@[A-Za-z0-9.-]+", r"colou?r", r"\x41+",
     r"to:([^\r\n]+)\r\n", r"a|", r"|a", r"(|a)b", r"a{3,}", r"[^\x00-\x7f]+", r"é", r"\D+", r"\W", r"\S+",
+    # (?i): ASCII letters only in byte mode
+    r"(?i)abc", r"(?i)subject:[^\r\n]+", r"(?i:from):[a-z]+", r"a(?i:b)c", r"(?i)[^a-c]+", r"(?i)[x-z]+|colou?r", r"(?i)\x41+b", r"(?i)é",
 ]
 HAYS = [b"", b"a", b"abc", b"aaa", b"abcabc", b"xabcx", b"aabab", b"babb", b"ab\nab", b"xyz", b"a b  c\r\n",
         b"from:alice@example.com\r\nto:bob@example.net\r\nsubject:hi there\r\n", b"12-34 x 5", b"colour color",
         b"AAA a", b"caf\xc3\xa9 \xc3\xa9\xc3\xa9", b"a]a]", b"a.b axb", b"aaaa", b"aaab", b"\x00\xff\x80", b"abb abb",
-        b"abababab", b"x" * 70 + b"abc" + b"y" * 70]
+        b"abababab", b"x" * 70 + b"abc" + b"y" * 70, b"ABC aBc abC", b"From:Alice SUBJECT:Hi There\r\nfrom:bob", b"XYZ Colour COLOR aBC",
+        b"caf\xc3\x89 \xc3\xa9"]
 
 
 def py_pattern(p: str) -> bytes:
@@ -163,9 +166,12 @@ UNI_PATTERNS = [
     r".", r".+", r"[^a]+", r"[^\r\n]+", r"\w+", r"\d+", r"\s+", r"\W+", r"\D", r"\S+", r"é+", r"[α-ω]+", r"[a-zà-ÿ]+", r"[^\x00-\x7f]+",
     r"x*", r"", r"a?", r"from:[^\r\n]*<(\w+)@(\w+)\.com>", r"subject:.*\r\n", r"\w+@\w+", r"[\w.-]+", r"(?-u:[^a]+)", r"(?s:.+)",
     r"(?s).+", r"日本|語", r"\x{1F600}", r"[\x{1F600}-\x{1F64F}]+", r"a.b", r"[^\W\d]+",
+    # (?i): simple case folding over Unicode orbits (k K U+212A, s S U+017F, the three sigmas, U+00DF U+1E9E)
+    r"(?i)k+", r"(?i)straße", r"(?i)σ+", r"(?i)[a-z]+", r"(?i)[^k]+", r"(?i:é)+x", r"(?i)subject:\w+", r"a(?i:b)c", r"(?i)[à-ÿ]+", r"(?i)ǆ",
 ]
 UNI_HAYS = ["", "abc", "café au lait", "αβγ δ", "日本語 text", "a😀b", "٣٤٥ 12", "x y z", "from:Ünï <ünï@exämple.com>\r\n",
-            "subject:héllo wörld\r\n", "a\nb", "éé é", "naïve façade", "̀combining", "𝔘𝔫𝔦 𝔠𝔬𝔡𝔢", "a.b aéb a\nb"]
+            "subject:héllo wörld\r\n", "a\nb", "éé é", "naïve façade", "̀combining", "𝔘𝔫𝔦 𝔠𝔬𝔡𝔢", "a.b aéb a\nb",
+            "kK\u212a k", "STRASSE Straße STRAẞE ſtraße", "ΣΑΣ σας ςσΣ", "SUBJECT:Héllo Subject:wörld", "ÉÉx éÉX aBc abc", "ǄǅǆK\u017fs"]
 
 
 def rust_find_iter_unicode(pat: str, text: str):
@@ -206,6 +212,27 @@ def test_unicode_mode_matches_the_regex_module(oracle, pat):
         n, spans = oracle.find_iter(rid, hay, 256)
         assert n >= 0, (pat, text)
         assert spans == rust_find_iter_unicode(pat, text), (pat, text)
+
+
+def test_case_folding_orbits_follow_casefolding_txt(oracle):
+    """(?i) folds with CaseFolding.txt's simple mappings (statuses C + S), as regex-syntax does: U+0130 and U+0131 — which
+    have only Turkic (T) and full (F) mappings — fold with nothing (the `regex` module, the pin of the test above, treats
+    the four I's as one letter, so this corner is checked against the table's own statement instead); U+212A folds with
+    k, U+017F with s, U+1E9E with U+00DF."""
+    orbits = {frozenset(o) for o in rc._fold_orbits()}
+    assert frozenset({0x4B, 0x6B, 0x212A}) in orbits and frozenset({0x53, 0x73, 0x17F}) in orbits
+    assert frozenset({0xDF, 0x1E9E}) in orbits and frozenset({0x3A3, 0x3C2, 0x3C3}) in orbits
+    assert not any(0x130 in o or 0x131 in o for o in orbits)
+    assert frozenset({0x49, 0x69}) in orbits
+    d = rc.create_dfa("(?i)i+", unicode=True)
+    rid = oracle.dfa_register(d.fwd, d.bwd)
+    hay = "İi ıI".encode("utf-8")
+    n, spans = oracle.find_iter(rid, hay, 16)
+    assert spans == [(2, 3), (6, 7)]
+    # byte mode: ASCII letters only, whatever the bytes above 0x7F are
+    d = rc.create_dfa("(?i)é", unicode=False)
+    rid = oracle.dfa_register(d.fwd, d.bwd)
+    assert oracle.find_iter(rid, "É é".encode("utf-8"), 16)[1] == [(3, 5)]
 
 
 def test_unicode_classes_never_match_invalid_utf8(oracle):

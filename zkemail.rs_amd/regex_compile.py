@@ -9,12 +9,13 @@ DFA), not byte-identical tables.  Two modes: ``unicode=True`` is regex-automata'
 one the reference compiles with — ``.``, classes, ``\\d \\w \\s`` and negations range over Unicode scalar
 values and become UTF-8 byte-sequence automata, flags.is_utf8 = 1; ``unicode=False`` is ``(?-u)``
 throughout: bytes, flags.is_utf8 = 0.  No ``\\b`` (a dense DFA cannot hold a Unicode word boundary in
-the reference either), no case-insensitive flag.
+the reference either).
 
 Supported syntax: literals, escapes (\\d \\w \\s \\D \\W \\S \\n \\r \\t \\f \\v \\0 \\xHH and escaped
 punctuation), ``.``, classes ``[a-z0-9_]`` / ``[^...]``, groups ``( )`` ``(?: )``, alternation,
 greedy and lazy ``* + ? {m} {m,} {m,n}``, ``^`` and ``$`` (text anchors, not multi-line), ``\\x{HHHH}``, non-ASCII
-literals and class members, the inline flags ``(?s) (?-s) (?u) (?-u)`` and their scoped forms.
+literals and class members, the inline flags ``(?s) (?-s) (?u) (?-u) (?i) (?-i)`` and their scoped forms
+(``(?i)``: regex-syntax's simple case folding — Unicode orbits in Unicode mode, ASCII letters in byte mode).
 """
 from __future__ import annotations
 
@@ -80,6 +81,54 @@ def _negate(r: Ranges, top: int) -> Ranges:
     if nxt <= top:
         out.append((nxt, top))
     return out
+
+
+_FOLD_ORBITS: Optional[List[Tuple[int, ...]]] = None
+
+
+def _fold_orbits() -> List[Tuple[int, ...]]:
+    """Simple case folding (CaseFolding.txt statuses C + S, what regex-syntax folds with) as orbits of more than one scalar
+    value.  Python has no table of it: `str.casefold` is C + F, so a one-character result is the C mapping; where the full
+    folding is several characters the S mapping, when there is one, is the one-character `lower()` (U+1E9E -> U+00DF, the
+    Greek capitals with ypogegrammeni); U+0130 has neither and stays alone, U+0131 folds to itself."""
+    global _FOLD_ORBITS
+    if _FOLD_ORBITS is None:
+        by_key: Dict[int, List[int]] = {}
+        for cp in range(MAXCP + 1):
+            if 0xD800 <= cp <= 0xDFFF:
+                continue
+            ch = chr(cp)
+            f = ch.casefold()
+            if len(f) != 1:
+                f = ch.lower()
+                if len(f) != 1:
+                    f = ch
+            k = ord(f)
+            if k != cp:
+                by_key.setdefault(k, [k]).append(cp)
+        _FOLD_ORBITS = [tuple(sorted(set(v))) for v in by_key.values()]
+    return _FOLD_ORBITS
+
+
+def _case_fold(r: Ranges, unicode: bool) -> Ranges:
+    """The class closed under simple case folding ((?i); regex-syntax ClassUnicode / ClassBytes::case_fold_simple)."""
+    import bisect
+    r = _norm(r)
+    los = [lo for lo, _ in r]
+
+    def has(cp: int) -> bool:
+        k = bisect.bisect_right(los, cp) - 1
+        return k >= 0 and r[k][1] >= cp
+    extra: Ranges = []
+    if unicode:
+        for orbit in _fold_orbits():
+            if any(has(c) for c in orbit):
+                extra += [(c, c) for c in orbit]
+    else:
+        for c in range(26):
+            if has(0x41 + c) or has(0x61 + c):
+                extra += [(0x41 + c, 0x41 + c), (0x61 + c, 0x61 + c)]
+    return _norm(list(r) + extra)
 
 
 def _unicode_class(name: str) -> Ranges:
@@ -208,7 +257,7 @@ class _Parser:
     """regex-syntax's surface, the part e-mail patterns use.  unicode=True (regex-automata's default, what
     helpers/src/regex.rs:20 builds with): `.`, classes, \\d \\w \\s and their negations range over Unicode scalar values and
     compile to UTF-8 byte sequences — a negated class never matches a stray byte >= 0x80.  unicode=False: bytes.
-    Inline flags: (?s) (?-s) (?u) (?-u) and the scoped forms (?s:...) (?-u:...)."""
+    Inline flags: (?s) (?-s) (?u) (?-u) (?i) (?-i) and the scoped forms (?s:...) (?-u:...) (?i:...)."""
 
     def __init__(self, pat: str, unicode: bool = False):
         self.s = pat
@@ -216,6 +265,7 @@ class _Parser:
         self.ngroups = 0
         self.unicode = unicode
         self.dotall = False
+        self.icase = False
 
     @property
     def top(self) -> int:
@@ -236,12 +286,12 @@ class _Parser:
         return n
 
     def alt(self) -> Node:
-        saved = (self.unicode, self.dotall)                   # (?flags) lasts to the end of the enclosing group
+        saved = (self.unicode, self.dotall, self.icase)       # (?flags) lasts to the end of the enclosing group
         branches = [self.cat()]
         while self.peek() == "|":
             self.eat()
             branches.append(self.cat())
-        self.unicode, self.dotall = saved
+        self.unicode, self.dotall, self.icase = saved
         return branches[0] if len(branches) == 1 else Node("alt", kids=branches)
 
     def cat(self) -> Node:
@@ -330,10 +380,16 @@ class _Parser:
                 self.unicode = on
             elif ch == "s":
                 self.dotall = on
+            elif ch == "i":
+                self.icase = on
             else:
                 raise RegexSyntaxError(f"unsupported flag {ch!r}")
 
     def literal(self, c: str) -> Node:
+        if self.icase and (self.unicode or ord(c) < 0x80):
+            folded = _case_fold([(ord(c), ord(c))], self.unicode)
+            if folded != [(ord(c), ord(c))]:
+                return _class_node(folded, self.unicode)
         b = c.encode("utf-8")
         if len(b) == 1:
             return Node("lit", byteset=frozenset(b))
@@ -350,10 +406,10 @@ class _Parser:
                 if m.group(2) == ")":                         # (?flags): applies to the rest of the enclosing group
                     self.flags(m.group(1))
                     return None
-                saved = (self.unicode, self.dotall)
+                saved = (self.unicode, self.dotall, self.icase)
                 self.flags(m.group(1))                        # (?flags:...) and (?:...)
                 n = self.alt()
-                self.unicode, self.dotall = saved
+                self.unicode, self.dotall, self.icase = saved
             else:
                 self.ngroups += 1
                 n = self.alt()
@@ -373,7 +429,7 @@ class _Parser:
             r = self.escape()
             if r is None:
                 raise RegexSyntaxError("non-ASCII escape")
-            return _class_node(r, self.unicode)
+            return _class_node(_case_fold(r, self.unicode) if self.icase else r, self.unicode)
         if c in "*+?{":
             if c == "{":
                 return Node("lit", byteset=frozenset([0x7B]))
@@ -422,6 +478,8 @@ class _Parser:
             else:
                 items += lo_set
         r = _norm(items)
+        if self.icase:
+            r = _case_fold(r, self.unicode)                   # folded first, negated second (regex-syntax's order)
         return _class_node(_negate(r, self.top) if neg else r, self.unicode)
 
 
