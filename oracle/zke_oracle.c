@@ -958,9 +958,12 @@ static int dfa_parse(const uint8_t* b, size_t n, dfa_t* d) {
   NEED(4); if (rd32(b + p) != 0xFEFF) return -1; p += 4;
   NEED(4); if (rd32(b + p) != 2) return -1; p += 4;
   NEED(4); p += 4; /* unused */
-  NEED(12);
-  d->has_empty = rd32(b + p); d->is_utf8 = rd32(b + p + 4); d->always_anchored = rd32(b + p + 8);
-  p += 12;
+  /* Flags::from_bytes: ONE u32 bit set — bit 0 has_empty, bit 1 is_utf8, bit 2 is_always_start_anchored (other bits ignored).
+   * SURVEY Appendix A.3 recalled three u32s here; blobs written by regex-automata itself (tests/golden/regex_automata_*.dfa)
+   * show one, and everything behind it as A.3 has it. */
+  NEED(4);
+  { uint32_t fl = rd32(b + p); d->has_empty = fl & 1u; d->is_utf8 = (fl >> 1) & 1u; d->always_anchored = (fl >> 2) & 1u; }
+  p += 4;
   /* transition table */
   NEED(8 + 256);
   d->state_len = rd32(b + p); d->stride2 = rd32(b + p + 4); p += 8;

@@ -61,6 +61,27 @@ def test_regex_status_paths_parity(engine, oracle):
     assert int(g2[0]["status"]) == A.ZKE_DFA_DECODE_FAIL
 
 
+def test_blobs_written_by_regex_automata_itself_deserialise(engine, oracle):
+    """The engine's parse_dfa_blob (dense::DFA::from_bytes restated, csrc/pipeline.hip.h) on the two dense DFAs that
+    regex-automata itself serialised (tests/golden/regex_automata_ws_anchored_*.dfa, tests/test_regex_automata_blobs.py):
+    they register as valid — an e-mail using them does NOT report ZKE_DFA_DECODE_FAIL (the pair is anchored-only, so the
+    search itself stops at the start state; engine and oracle agree on what that is) — while the same bytes with three flag
+    words, the layout SURVEY Appendix A.3 recalled, do."""
+    import struct
+    from test_regex_automata_blobs import blob
+    inputs, wl, _ = synth.make_regex_workload("real-blob", 3, 600, n_header_parts=1, n_body_parts=0, seed=9)
+    fwd, rev = blob("fwd"), blob("rev")
+    real = [A.EmailWithRegex(i.email, A.RegexInfo([A.CompiledRegex(A.DFA(fwd, rev), None)], None)) for i in inputs]
+    got, exp, _, _ = both(engine, oracle, real)
+    assert_records_equal(got, exp, None, "real blobs")
+    assert all(int(x) != A.ZKE_DFA_DECODE_FAIL for x in got["status"])
+    old = fwd[:44] + struct.pack("<III", 0, 1, 0) + fwd[48:]
+    bad = [A.EmailWithRegex(i.email, A.RegexInfo([A.CompiledRegex(A.DFA(old, rev), None)], None)) for i in inputs]
+    g2, e2, _, _ = both(engine, oracle, bad)
+    assert_records_equal(g2, e2, None, "three flag words")
+    assert all(int(x) == A.ZKE_DFA_DECODE_FAIL for x in g2["status"])
+
+
 def test_first_signature_canonicalisation_parity(engine, oracle):
     c = [x for x in cases.build_cases() if x.name == "pass_two_signatures"][0]
     c2 = [x for x in cases.build_cases() if x.name == "pass_second_signature_after_failed_first"][0]

@@ -16,6 +16,7 @@ PATTERNS = [
     r"subject:[^\r\n]+\r\n", r"a??b", r"a+?", r"(a+)(b+)", r"[A-Za-z0-9._%+-]+@[A-Za-z0-9.-]+", r"colou?r", r"\x41+",
     r"to:([^\r\n]+)\r\n", r"a|", r"|a", r"(|a)b", r"a{3,}", r"[^\x00-\x7f]+", r"é", r"\D+", r"\W", r"\S+",
     # (?i): ASCII letters only in byte mode
+    r"\Aabc", r"abc\z", r"\Aa*\z", r"[[:alpha:]]+", r"[[:^alpha:][:digit:]]+", r"[[:upper:][:digit:]_]+x?", r"(?i)[[:lower:]]+",
     r"(?i)abc", r"(?i)subject:[^\r\n]+", r"(?i:from):[a-z]+", r"a(?i:b)c", r"(?i)[^a-c]+", r"(?i)[x-z]+|colou?r", r"(?i)\x41+b", r"(?i)é",
 ]
 HAYS = [b"", b"a", b"abc", b"aaa", b"abcabc", b"xabcx", b"aabab", b"babb", b"ab\nab", b"xyz", b"a b  c\r\n",
@@ -27,7 +28,29 @@ HAYS = [b"", b"a", b"abc", b"aaa", b"abcabc", b"xabcx", b"aabab", b"babb", b"ab\
 
 def py_pattern(p: str) -> bytes:
     # Rust `$` is end-of-haystack only; Python's also fires before a final "\n"
-    return p.replace("$", r"\Z").encode("utf-8")
+    return _posix(p.replace("$", r"\Z").replace(r"\z", r"\Z")).encode("utf-8")
+
+
+_POSIX_PY = {"alpha": "A-Za-z", "digit": "0-9", "upper": "A-Z", "lower": "a-z"}
+
+
+def _posix(p: str) -> str:
+    """[:name:] / [:^name:] inside a bracket expression, spelled for Python's re (which has no POSIX classes)."""
+    import re as _re
+    def one(m):
+        body = _POSIX_PY[m.group(2)]
+        if not m.group(1):
+            return body
+        # a negated POSIX class inside a positive bracket: everything but the ranges
+        rs = [(ord(body[i]), ord(body[i + 2])) for i in range(0, len(body), 3)]
+        out, nxt = [], 0
+        for lo, hi in sorted(rs):
+            if lo > nxt:
+                out.append(f"\\x{nxt:02x}-\\x{lo - 1:02x}")
+            nxt = hi + 1
+        out.append(f"\\x{nxt:02x}-\\xff")
+        return "".join(out)
+    return _re.sub(r"\[:(\^?)([a-z]+):\]", one, p)
 
 
 def rust_find_iter(pat: str, hay: bytes):
@@ -85,22 +108,22 @@ def test_random_patterns_vs_python_re(oracle):
 
 
 def test_wire_format_layout():
-    """SURVEY.md Appendix A.3, field by field, on a small DFA."""
+    """The wire layout, field by field, on a small DFA (SURVEY.md Appendix A.3 with the one correction the blobs regex-automata
+    itself wrote brought: the flags are one u32 bit set — tests/test_regex_automata_blobs.py)."""
     d = rc.create_dfa("ab+")
     b = d.fwd
     assert b[:29] == b"rust-regex-automata-dfa-dense" and b[29:32] == b"\0\0\0"
     assert struct.unpack_from("<III", b, 32) == (0xFEFF, 2, 0)
-    has_empty, is_utf8, anch = struct.unpack_from("<III", b, 44)
-    assert (has_empty, is_utf8, anch) == (0, 0, 0)
-    state_len, stride2 = struct.unpack_from("<II", b, 56)
-    classes = b[64:320]
+    assert struct.unpack_from("<I", b, 44)[0] == 0                                # flags: has_empty | is_utf8 << 1 | always_anchored << 2
+    state_len, stride2 = struct.unpack_from("<II", b, 48)
+    classes = b[56:312]
     alphabet_len = classes[255] + 2
     assert alphabet_len <= (1 << stride2) and classes[ord("a")] != classes[ord("b")] != classes[ord("c")]
     assert all(classes[i] <= classes[i + 1] for i in range(255))                 # contiguous ranges
-    tbl_off = 320
+    tbl_off = 312
     tbl = struct.unpack_from(f"<{state_len << stride2}I", b, tbl_off)
     assert all(t % (1 << stride2) == 0 and t < len(tbl) for t in tbl)             # premultiplied ids
-    assert all(t == 0 for t in tbl[:1 << stride2])                                # state 0 is the dead state
+    assert all(t == 0 for t in tbl[:2 << stride2])                                # state 0 is the dead state, state 1 the quit state
     p = tbl_off + 4 * len(tbl)
     kind = struct.unpack_from("<I", b, p)[0]
     assert kind == 0                                                              # StartKind::Both
@@ -110,8 +133,8 @@ def test_wire_format_layout():
     assert stride == 6 and plen == 0xFFFFFFFF
     # the reverse DFA is anchored-only
     rb = d.bwd
-    rstate_len, rstride2 = struct.unpack_from("<II", rb, 56)
-    rp = 320 + 4 * (rstate_len << rstride2)
+    rstate_len, rstride2 = struct.unpack_from("<II", rb, 48)
+    rp = 312 + 4 * (rstate_len << rstride2)
     assert struct.unpack_from("<I", rb, rp)[0] == 2
     assert len(b) % 4 == 0 and len(rb) % 4 == 0
 
@@ -124,7 +147,7 @@ def test_invalid_blobs_are_rejected(oracle):
     bad_endian = d.fwd[:32] + struct.pack("<I", 0xFFFE0000) + d.fwd[36:]
     bad_version = d.fwd[:36] + struct.pack("<I", 3) + d.fwd[40:]
     truncated = d.fwd[:-8]
-    bad_id = bytearray(d.fwd); struct.pack_into("<I", bad_id, 320 + 4 * 9, 3)    # a transition that is not a multiple of stride
+    bad_id = bytearray(d.fwd); struct.pack_into("<I", bad_id, 312 + 4 * 9, 3)    # a transition that is not a multiple of stride
     for blob in (bad_label, bad_endian, bad_version, truncated, bytes(bad_id), b""):
         rid = oracle.dfa_register(blob, d.bwd)
         assert oracle.find_iter(rid, b"xabc")[0] == -2
@@ -205,7 +228,7 @@ def rust_find_iter_unicode(pat: str, text: str):
 def test_unicode_mode_matches_the_regex_module(oracle, pat):
     pytest.importorskip("regex")
     d = rc.create_dfa(pat, unicode=True)
-    assert struct.unpack_from("<III", d.fwd, 44)[1] == 1          # flags.is_utf8
+    assert struct.unpack_from("<I", d.fwd, 44)[0] & 2             # flags.is_utf8
     rid = oracle.dfa_register(d.fwd, d.bwd)
     for text in UNI_HAYS:
         hay = text.encode("utf-8")
@@ -277,6 +300,6 @@ def test_compile_regex_parts_unicode_mirror():
     inp = "from:Zoë <zoë@exämple.com>\r\nsubject:grüße\r\n".encode()
     parts = rc.compile_regex_parts([rc.RegexPattern(r"from:[^\r\n]*<(\w+)@([\w.]+)>", [1, 2]), rc.RegexPattern(r"subject:(.*)\r\n", [1])], inp)
     assert parts[0].captures == ["zoë", "exämple.com"] and parts[1].captures == ["grüße"]
-    assert struct.unpack_from("<III", parts[0].verify_re.fwd, 44)[1] == 1
+    assert struct.unpack_from("<I", parts[0].verify_re.fwd, 44)[0] & 2                     # flags.is_utf8
     bytes_mode = rc.compile_regex_parts([rc.RegexPattern(r"subject:([^\r\n]*)\r\n", [1])], inp, unicode=False)
-    assert bytes_mode[0].captures == ["grüße"] and struct.unpack_from("<III", bytes_mode[0].verify_re.fwd, 44)[1] == 0
+    assert bytes_mode[0].captures == ["grüße"] and not struct.unpack_from("<I", bytes_mode[0].verify_re.fwd, 44)[0] & 2

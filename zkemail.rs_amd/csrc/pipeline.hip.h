@@ -276,9 +276,11 @@ bool parse_dfa_blob(const uint8_t* b, size_t n, HostDfa& h) {
   if (!need(4) || rd32(b + p) != 0xFEFF) return false; p += 4;
   if (!need(4) || rd32(b + p) != 2) return false; p += 4;
   if (!need(4)) return false; p += 4;
-  if (!need(12)) return false;
-  d.has_empty = rd32(b + p); d.is_utf8 = rd32(b + p + 4); d.always_anchored = rd32(b + p + 8);
-  p += 12;
+  // Flags::from_bytes: ONE u32 bit set — bit 0 has_empty, bit 1 is_utf8, bit 2 is_always_start_anchored — as the blobs
+  // regex-automata itself wrote show (tests/golden/regex_automata_*.dfa; SURVEY Appendix A.3 recalled three u32s)
+  if (!need(4)) return false;
+  { const uint32_t fl = rd32(b + p); d.has_empty = fl & 1u; d.is_utf8 = (fl >> 1) & 1u; d.always_anchored = (fl >> 2) & 1u; }
+  p += 4;
   if (!need(8 + 256)) return false;
   d.state_len = rd32(b + p); d.stride2 = rd32(b + p + 4); p += 8;
   memcpy(d.classes, b + p, 256); p += 256;

@@ -13,7 +13,8 @@ the reference either).
 
 Supported syntax: literals, escapes (\\d \\w \\s \\D \\W \\S \\n \\r \\t \\f \\v \\0 \\xHH and escaped
 punctuation), ``.``, classes ``[a-z0-9_]`` / ``[^...]``, groups ``( )`` ``(?: )``, alternation,
-greedy and lazy ``* + ? {m} {m,} {m,n}``, ``^`` and ``$`` (text anchors, not multi-line), ``\\x{HHHH}``, non-ASCII
+greedy and lazy ``* + ? {m} {m,} {m,n}``, ``^`` ``$`` ``\\A`` ``\\z`` (text anchors, not multi-line), POSIX bracket classes
+``[[:alpha:]]`` ``[[:^digit:]]``, ``\\x{HHHH}``, non-ASCII
 literals and class members, the inline flags ``(?s) (?-s) (?u) (?-u) (?i) (?-i)`` and their scoped forms
 (``(?i)``: regex-syntax's simple case folding — Unicode orbits in Unicode mode, ASCII letters in byte mode).
 """
@@ -59,6 +60,13 @@ _ASCII_CLASS: Dict[str, Ranges] = {
 # White_Space (PropList.txt) — what regex-syntax's Unicode \s is
 _UNI_SPACE: Ranges = [(0x09, 0x0D), (0x20, 0x20), (0x85, 0x85), (0xA0, 0xA0), (0x1680, 0x1680), (0x2000, 0x200A), (0x2028, 0x2029),
                       (0x202F, 0x202F), (0x205F, 0x205F), (0x3000, 0x3000)]
+_POSIX_CLASS: Dict[str, Ranges] = {
+    "alnum": [(0x30, 0x39), (0x41, 0x5A), (0x61, 0x7A)], "alpha": [(0x41, 0x5A), (0x61, 0x7A)], "ascii": [(0x00, 0x7F)],
+    "blank": [(0x09, 0x09), (0x20, 0x20)], "cntrl": [(0x00, 0x1F), (0x7F, 0x7F)], "digit": [(0x30, 0x39)], "graph": [(0x21, 0x7E)],
+    "lower": [(0x61, 0x7A)], "print": [(0x20, 0x7E)], "punct": [(0x21, 0x2F), (0x3A, 0x40), (0x5B, 0x60), (0x7B, 0x7E)],
+    "space": [(0x09, 0x0D), (0x20, 0x20)], "upper": [(0x41, 0x5A)], "word": [(0x30, 0x39), (0x41, 0x5A), (0x5F, 0x5F), (0x61, 0x7A)],
+    "xdigit": [(0x30, 0x39), (0x41, 0x46), (0x61, 0x66)],
+}
 _UNI_CACHE: Dict[str, Ranges] = {}
 
 
@@ -426,6 +434,12 @@ class _Parser:
         if c == "$":
             return Node("end")
         if c == "\\":
+            if self.peek() == "A":                            # \A, \z: the text anchors by their other names
+                self.eat()
+                return Node("start")
+            if self.peek() == "z":
+                self.eat()
+                return Node("end")
             r = self.escape()
             if r is None:
                 raise RegexSyntaxError("non-ASCII escape")
@@ -454,6 +468,14 @@ class _Parser:
             if c == "]" and not first:
                 break
             first = False
+            if c == "[" and self.peek() == ":":                # [[:alpha:]] ... — ASCII classes in both modes (regex-syntax)
+                m = _pyre.match(r":(\^?)([a-z]+):\]", self.s[self.i:])
+                if not m or m.group(2) not in _POSIX_CLASS:
+                    raise RegexSyntaxError("unknown POSIX class")
+                self.i += m.end()
+                pr = _POSIX_CLASS[m.group(2)]
+                items += _negate(pr, self.top) if m.group(1) else pr
+                continue
             if c == "\\":
                 lo_set = self.escape()
                 if lo_set is None:
@@ -704,10 +726,12 @@ def _determinize(nfa: _NFA, start: int, classes: List[int], *, reverse: bool, le
 
 
 def _serialize(b: _Built, *, start_kind: int, has_empty: bool, is_utf8: bool, always_anchored: bool) -> bytes:
+    """dense::DFA::write_to, as the blobs regex-automata itself wrote lay it out (tests/golden/regex_automata_*.dfa): label,
+    endianness, version, one unused u32, the flags as ONE u32 bit set, transition table, start table, match states, special,
+    accelerators, quit set.  State order as there: dead, quit (never entered here: the quit set is empty), match states, the rest."""
     n = len(b.table)
-    # layout: dead, match states, everything else (Special: only dead + match states are special)
     order = [0] + [i for i in range(1, n) if b.is_match[i]] + [i for i in range(1, n) if not b.is_match[i]]
-    newidx = {old: new for new, old in enumerate(order)}
+    newidx = {old: (new if new == 0 else new + 1) for new, old in enumerate(order)}      # index 1 is the quit state
     stride2 = max(1, (b.alphabet_len - 1).bit_length())
     stride = 1 << stride2
     sid = lambda i: newidx[i] << stride2   # noqa: E731
@@ -715,10 +739,10 @@ def _serialize(b: _Built, *, start_kind: int, has_empty: bool, is_utf8: bool, al
     out = bytearray()
     out += LABEL + b"\0" * (32 - len(LABEL))
     out += struct.pack("<III", 0xFEFF, 2, 0)
-    out += struct.pack("<III", int(has_empty), int(is_utf8), int(always_anchored))
-    out += struct.pack("<II", n, stride2)
+    out += struct.pack("<I", int(has_empty) | (int(is_utf8) << 1) | (int(always_anchored) << 2))
+    out += struct.pack("<II", n + 1, stride2)
     out += bytes(b.classes)
-    tbl = [0] * (n * stride)
+    tbl = [0] * ((n + 1) * stride)
     for old in range(n):
         base = newidx[old] * stride
         for c in range(b.alphabet_len):
@@ -743,10 +767,11 @@ def _serialize(b: _Built, *, start_kind: int, has_empty: bool, is_utf8: bool, al
     for k in range(nm):
         out += struct.pack("<II", k, 1)
     out += struct.pack("<II", 1, nm) + struct.pack(f"<{nm}I", *([0] * nm))
-    # special
-    min_match = (1 << stride2) if nm else DEAD
-    max_match = (nm << stride2) if nm else DEAD
-    out += struct.pack("<8I", max_match, DEAD, min_match, max_match, DEAD, DEAD, DEAD, DEAD)
+    # special: max, quit_id, min_match, max_match, min_accel, max_accel, min_start, max_start
+    quit_id = stride
+    min_match = (2 << stride2) if nm else DEAD
+    max_match = ((nm + 1) << stride2) if nm else DEAD
+    out += struct.pack("<8I", max_match if nm else quit_id, quit_id, min_match, max_match, DEAD, DEAD, DEAD, DEAD)
     out += struct.pack("<I", 0)          # accelerators: none
     out += b"\0" * 32                    # quit set: empty
     return bytes(out)
