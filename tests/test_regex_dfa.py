@@ -16,6 +16,9 @@ PATTERNS = [
     r"subject:[^\r\n]+\r\n", r"a??b", r"a+?", r"(a+)(b+)", r"[A-Za-z0-9._%+-]+@[A-Za-z0-9.-]+", r"colou?r", r"\x41+",
     r"to:([^\r\n]+)\r\n", r"a|", r"|a", r"(|a)b", r"a{3,}", r"[^\x00-\x7f]+", r"é", r"\D+", r"\W", r"\S+",
     # (?i): ASCII letters only in byte mode
+    # look-around: (?m) line anchors (LF), the ASCII word boundary (byte mode: \b is (?-u:\b))
+    r"(?m)^a", r"(?m)b$", r"(?m)^$", r"(?m:^[a-z]+$)", r"(?m)^subject:[^\r\n]+", r"\bab\b", r"\b", r"\B", r"a\b", r"\Ba", r"\b\w+\b", r"x*\b",
+    r"(?m)^\b|\b$", r"[a-c]\b.", r"(\bfoo|bar\b)+", r"\b[0-9]+\B", r"(?m)\r$", r"(?m)(^|,)b",
     r"\Aabc", r"abc\z", r"\Aa*\z", r"[[:alpha:]]+", r"[[:^alpha:][:digit:]]+", r"[[:upper:][:digit:]_]+x?", r"(?i)[[:lower:]]+",
     r"(?i)abc", r"(?i)subject:[^\r\n]+", r"(?i:from):[a-z]+", r"a(?i:b)c", r"(?i)[^a-c]+", r"(?i)[x-z]+|colou?r", r"(?i)\x41+b", r"(?i)é",
 ]
@@ -23,12 +26,15 @@ HAYS = [b"", b"a", b"abc", b"aaa", b"abcabc", b"xabcx", b"aabab", b"babb", b"ab\
         b"from:alice@example.com\r\nto:bob@example.net\r\nsubject:hi there\r\n", b"12-34 x 5", b"colour color",
         b"AAA a", b"caf\xc3\xa9 \xc3\xa9\xc3\xa9", b"a]a]", b"a.b axb", b"aaaa", b"aaab", b"\x00\xff\x80", b"abb abb",
         b"abababab", b"x" * 70 + b"abc" + b"y" * 70, b"ABC aBc abC", b"From:Alice SUBJECT:Hi There\r\nfrom:bob", b"XYZ Colour COLOR aBC",
-        b"caf\xc3\x89 \xc3\xa9"]
+        b"caf\xc3\x89 \xc3\xa9", b"a\nab\nb\n\nabc", b"foo bar foobar barfoo", b"ab ab_ab ab-ab 12ab", b"\n", b"\n\n", b"to:x\nsubject:hi\r\nSubject:no\nsubject:yes",
+        b"x,b\nb,b", b"ab", b"a b", b"\xffab\xff", b"7 77 x77 77x"]
 
 
 def py_pattern(p: str) -> bytes:
     # Rust `$` is end-of-haystack only; Python's also fires before a final "\n"
-    return _posix(p.replace("$", r"\Z").replace(r"\z", r"\Z")).encode("utf-8")
+    if "(?m" not in p:
+        p = p.replace("$", r"\Z")
+    return _posix(p.replace(r"\z", r"\Z")).encode("utf-8")
 
 
 _POSIX_PY = {"alpha": "A-Za-z", "digit": "0-9", "upper": "A-Z", "lower": "a-z"}
@@ -81,6 +87,11 @@ def test_find_iter_matches_python_re(oracle, pat):
     for hay in HAYS:
         n, spans = oracle.find_iter(rid, hay, 256)
         assert n >= 0, (pat, hay)
+        if hay == b"" and "\\B" in pat:
+            # Python's re never lets \B match in an empty string (a documented quirk); in Rust both sides of the only
+            # position are "not a word byte", so not-a-boundary holds
+            assert spans == ([(0, 0)] if pat in (r"\B", r"x*\B") else []), pat
+            continue
         assert spans == rust_find_iter(pat, hay), (pat, hay)
 
 
@@ -190,6 +201,7 @@ UNI_PATTERNS = [
     r"x*", r"", r"a?", r"from:[^\r\n]*<(\w+)@(\w+)\.com>", r"subject:.*\r\n", r"\w+@\w+", r"[\w.-]+", r"(?-u:[^a]+)", r"(?s:.+)",
     r"(?s).+", r"日本|語", r"\x{1F600}", r"[\x{1F600}-\x{1F64F}]+", r"a.b", r"[^\W\d]+",
     # (?i): simple case folding over Unicode orbits (k K U+212A, s S U+017F, the three sigmas, U+00DF U+1E9E)
+    r"(?m)^\w+$", r"(?m)^[^\n]*é$", r"(?m:^)x|y(?m:$)",
     r"(?i)k+", r"(?i)straße", r"(?i)σ+", r"(?i)[a-z]+", r"(?i)[^k]+", r"(?i:é)+x", r"(?i)subject:\w+", r"a(?i:b)c", r"(?i)[à-ÿ]+", r"(?i)ǆ",
 ]
 UNI_HAYS = ["", "abc", "café au lait", "αβγ δ", "日本語 text", "a😀b", "٣٤٥ 12", "x y z", "from:Ünï <ünï@exämple.com>\r\n",
@@ -202,7 +214,7 @@ def rust_find_iter_unicode(pat: str, text: str):
     end advances by one code point (UTF-8 mode)."""
     import regex
     pat = re.sub(r"\\x\{([0-9A-Fa-f]+)\}", lambda m: chr(int(m.group(1), 16)), pat)       # the regex module spells it \U0001F600
-    rx = regex.compile(pat.replace("$", r"\Z"))
+    rx = regex.compile(pat if "(?m" in pat else pat.replace("$", r"\Z"))
     off = [0]
     for ch in text:
         off.append(off[-1] + len(ch.encode("utf-8")))
@@ -235,6 +247,21 @@ def test_unicode_mode_matches_the_regex_module(oracle, pat):
         n, spans = oracle.find_iter(rid, hay, 256)
         assert n >= 0, (pat, text)
         assert spans == rust_find_iter_unicode(pat, text), (pat, text)
+
+
+def test_word_boundary_modes(oracle):
+    """A Unicode \\b cannot be built into a dense DFA — dense::Builder fails, so the reference's compile_regex_parts
+    (helpers/src/regex.rs:20) returns Err for such a pattern; the ASCII one, (?-u:\\b), can, also inside a Unicode pattern."""
+    for pat in (r"\bfoo", r"foo\B", r"(?i)\bx"):
+        with pytest.raises(rc.RegexSyntaxError):
+            rc.create_dfa(pat, unicode=True)
+    d = rc.create_dfa(r"(?-u:\b)\w+(?-u:\b)", unicode=True)
+    rid = oracle.dfa_register(d.fwd, d.bwd)
+    hay = "héllo wörld x1".encode("utf-8")
+    assert oracle.find_iter(rid, hay, 16)[1] == [(0, 6), (7, 13), (14, 16)]          # \w is Unicode, the boundary ASCII: inside "héllo"
+    d = rc.create_dfa(r"(?-u:\b)l+", unicode=True)                                   # "é" is not an ASCII word byte: a boundary before "llo"
+    rid = oracle.dfa_register(d.fwd, d.bwd)
+    assert oracle.find_iter(rid, hay, 16)[1] == [(3, 5)]
 
 
 def test_case_folding_orbits_follow_casefolding_txt(oracle):

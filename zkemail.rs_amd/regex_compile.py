@@ -8,8 +8,8 @@ DFA with one-byte-delayed match states and an EOI transition; anchored, match-ki
 DFA), not byte-identical tables.  Two modes: ``unicode=True`` is regex-automata's default syntax, the
 one the reference compiles with — ``.``, classes, ``\\d \\w \\s`` and negations range over Unicode scalar
 values and become UTF-8 byte-sequence automata, flags.is_utf8 = 1; ``unicode=False`` is ``(?-u)``
-throughout: bytes, flags.is_utf8 = 0.  No ``\\b`` (a dense DFA cannot hold a Unicode word boundary in
-the reference either).
+throughout: bytes, flags.is_utf8 = 0.  Look-around: ``^ $ \\A \\z``, ``(?m)`` line anchors (LF), the ASCII word boundary
+``(?-u:\\b)`` / ``(?-u:\\B)``; a Unicode ``\\b`` is an error, as it is for the reference (a dense DFA cannot hold one).
 
 Supported syntax: literals, escapes (\\d \\w \\s \\D \\W \\S \\n \\r \\t \\f \\v \\0 \\xHH and escaped
 punctuation), ``.``, classes ``[a-z0-9_]`` / ``[^...]``, groups ``( )`` ``(?: )``, alternation,
@@ -39,7 +39,7 @@ class RegexSyntaxError(ValueError):
 # ------------------------------------------------------------------ AST
 @dataclass
 class Node:
-    kind: str                     # lit, cat, alt, rep, start, end, empty, group
+    kind: str                     # lit, cat, alt, rep, empty, group; assertions: start, end, sol, eol, wb, nwb
     byteset: Optional[FrozenSet[int]] = None
     kids: Optional[List["Node"]] = None
     lo: int = 0
@@ -265,7 +265,7 @@ class _Parser:
     """regex-syntax's surface, the part e-mail patterns use.  unicode=True (regex-automata's default, what
     helpers/src/regex.rs:20 builds with): `.`, classes, \\d \\w \\s and their negations range over Unicode scalar values and
     compile to UTF-8 byte sequences — a negated class never matches a stray byte >= 0x80.  unicode=False: bytes.
-    Inline flags: (?s) (?-s) (?u) (?-u) (?i) (?-i) and the scoped forms (?s:...) (?-u:...) (?i:...)."""
+    Inline flags: (?s) (?u) (?i) (?m) and their negations, and the scoped forms (?s:...) (?-u:...) (?i:...) (?m:...)."""
 
     def __init__(self, pat: str, unicode: bool = False):
         self.s = pat
@@ -274,6 +274,7 @@ class _Parser:
         self.unicode = unicode
         self.dotall = False
         self.icase = False
+        self.multiline = False
 
     @property
     def top(self) -> int:
@@ -294,12 +295,12 @@ class _Parser:
         return n
 
     def alt(self) -> Node:
-        saved = (self.unicode, self.dotall, self.icase)       # (?flags) lasts to the end of the enclosing group
+        saved = (self.unicode, self.dotall, self.icase, self.multiline)       # (?flags) lasts to the end of the enclosing group
         branches = [self.cat()]
         while self.peek() == "|":
             self.eat()
             branches.append(self.cat())
-        self.unicode, self.dotall, self.icase = saved
+        self.unicode, self.dotall, self.icase, self.multiline = saved
         return branches[0] if len(branches) == 1 else Node("alt", kids=branches)
 
     def cat(self) -> Node:
@@ -338,8 +339,8 @@ class _Parser:
             greedy = True
             if self.peek() == "?":
                 self.eat(); greedy = False
-            if a.kind in ("start", "end"):
-                raise RegexSyntaxError("repetition of an anchor")
+            if a.kind in ("start", "end", "sol", "eol", "wb", "nwb"):
+                raise RegexSyntaxError("repetition of an assertion")
             a = Node("rep", kids=[a], lo=lo, hi=hi, greedy=greedy)
         return a
 
@@ -372,9 +373,7 @@ class _Parser:
         if c in _ESC_CHAR:
             return [(_ESC_CHAR[c], _ESC_CHAR[c])]
         if c in "bB":
-            # regex-automata cannot build a DFA with a Unicode word boundary either (dense::Builder errors), and the
-            # ASCII one, (?-u:\\b), needs look-behind state this compiler does not model
-            raise RegexSyntaxError("word boundaries are not supported")
+            raise RegexSyntaxError("word boundary inside a class")
         if c.isalnum():
             raise RegexSyntaxError(f"unsupported escape \\{c}")
         return [(ord(c), ord(c))] if (self.unicode or ord(c) < 0x80) else None
@@ -390,6 +389,8 @@ class _Parser:
                 self.dotall = on
             elif ch == "i":
                 self.icase = on
+            elif ch == "m":
+                self.multiline = on
             else:
                 raise RegexSyntaxError(f"unsupported flag {ch!r}")
 
@@ -414,10 +415,10 @@ class _Parser:
                 if m.group(2) == ")":                         # (?flags): applies to the rest of the enclosing group
                     self.flags(m.group(1))
                     return None
-                saved = (self.unicode, self.dotall, self.icase)
+                saved = (self.unicode, self.dotall, self.icase, self.multiline)
                 self.flags(m.group(1))                        # (?flags:...) and (?:...)
                 n = self.alt()
-                self.unicode, self.dotall, self.icase = saved
+                self.unicode, self.dotall, self.icase, self.multiline = saved
             else:
                 self.ngroups += 1
                 n = self.alt()
@@ -430,9 +431,9 @@ class _Parser:
         if c == ".":
             return _class_node([(0, self.top)] if self.dotall else _negate([(0x0A, 0x0A)], self.top), self.unicode)
         if c == "^":
-            return Node("start")
+            return Node("sol" if self.multiline else "start")
         if c == "$":
-            return Node("end")
+            return Node("eol" if self.multiline else "end")
         if c == "\\":
             if self.peek() == "A":                            # \A, \z: the text anchors by their other names
                 self.eat()
@@ -440,6 +441,12 @@ class _Parser:
             if self.peek() == "z":
                 self.eat()
                 return Node("end")
+            if self.peek() in ("b", "B"):
+                # The Unicode word boundary cannot be built into a dense DFA: dense::Builder fails on it, so the reference's
+                # compile_regex_parts (helpers/src/regex.rs:20) returns Err for such a pattern.  (?-u:\b) is the ASCII one.
+                if self.unicode:
+                    raise RegexSyntaxError("Unicode word boundary: regex-automata cannot build a dense DFA with it either; write (?-u:\\b)")
+                return Node("wb" if self.eat() == "b" else "nwb")
             r = self.escape()
             if r is None:
                 raise RegexSyntaxError("non-ASCII escape")
@@ -512,7 +519,7 @@ def _reverse(n: Node) -> Node:
         return Node(n.kind, kids=[_reverse(k) for k in n.kids])
     if n.kind == "rep":
         return Node("rep", kids=[_reverse(n.kids[0])], lo=n.lo, hi=n.hi, greedy=n.greedy)
-    return n   # lit / empty / start / end keep their meaning (start = start of haystack)
+    return n   # lit / empty / assertions keep their meaning (start = start of haystack): they are decided on (left, right) contexts
 
 
 def _always_start_anchored(n: Node) -> bool:
@@ -529,7 +536,7 @@ def _always_start_anchored(n: Node) -> bool:
 
 # ------------------------------------------------------------------ Thompson NFA (priority ordered)
 class _NFA:
-    # state kinds: ("byte", set, nxt) ("split", [nxt...]) ("start", nxt) ("end", nxt) ("match",)
+    # state kinds: ("byte", set, nxt) ("split", [nxt...]) ("look", kind, nxt) ("match",)
     def __init__(self):
         self.st: List[tuple] = []
 
@@ -555,10 +562,8 @@ class _NFA:
             return nxt
         if k == "alt":
             return self.add(("split", [self.build(kid, nxt) for kid in n.kids]))
-        if k == "start":
-            return self.add(("start", nxt))
-        if k == "end":
-            return self.add(("end", nxt))
+        if k in _LOOKS:
+            return self.add(("look", k, nxt))
         if k == "rep":
             kid, lo, hi, greedy = n.kids[0], n.lo, n.hi, n.greedy
             if hi is None:
@@ -577,8 +582,39 @@ class _NFA:
         raise AssertionError(k)
 
 
-def _closure(nfa: _NFA, seeds: Sequence[int], look_start: bool, look_end: bool) -> Tuple[int, ...]:
-    """Priority-ordered epsilon closure.  Assertion states whose look is not (yet) satisfied stay in the set."""
+# Look-around assertions and the context they look at.  A context is what lies on one side of a position: the edge of the
+# haystack, a line feed, an ASCII word byte, or any other byte.
+_LOOKS = ("start", "end", "sol", "eol", "wb", "nwb")      # \A ^ | \z $ | (?m)^ | (?m)$ | (?-u:\b) | (?-u:\B)
+EDGE, LF, WORD, OTHER = 0, 1, 2, 3
+
+
+def _ctx(byte: Optional[int]) -> int:
+    if byte is None:
+        return EDGE
+    if byte == 0x0A:
+        return LF
+    if byte == 0x5F or 0x30 <= byte <= 0x39 or 0x41 <= byte <= 0x5A or 0x61 <= byte <= 0x7A:
+        return WORD
+    return OTHER
+
+
+def _look_holds(kind: str, left: int, right: int) -> bool:
+    if kind == "start":
+        return left == EDGE
+    if kind == "end":
+        return right == EDGE
+    if kind == "sol":
+        return left in (EDGE, LF)
+    if kind == "eol":
+        return right in (EDGE, LF)
+    same = (left == WORD) == (right == WORD)
+    return not same if kind == "wb" else same
+
+
+def _closure(nfa: _NFA, seeds: Sequence[int], sides: Optional[Tuple[int, int]] = None) -> Tuple[int, ...]:
+    """Priority-ordered epsilon closure.  sides = (left, right): the contexts of the position are known and every assertion
+    is decided (a failed one ends its thread); sides = None: the byte behind the position has not been seen yet — assertion
+    states stay in the set and are decided by the next step, which is why match states are delayed by one byte."""
     out: List[int] = []
     seen = set()
     stack = list(reversed(seeds))
@@ -590,16 +626,11 @@ def _closure(nfa: _NFA, seeds: Sequence[int], look_start: bool, look_end: bool) 
         t = nfa.st[s]
         if t[0] == "split":
             stack.extend(reversed(t[1]))
-        elif t[0] == "start":
-            if look_start:
-                stack.append(t[1])
-            else:
+        elif t[0] == "look":
+            if sides is None:
                 out.append(s)
-        elif t[0] == "end":
-            if look_end:
-                stack.append(t[1])
-            else:
-                out.append(s)
+            elif _look_holds(t[1], sides[0], sides[1]):
+                stack.append(t[2])
         else:
             out.append(s)
     return tuple(out)
@@ -607,7 +638,7 @@ def _closure(nfa: _NFA, seeds: Sequence[int], look_start: bool, look_end: bool) 
 
 def _can_match_empty(n: Node) -> bool:
     k = n.kind
-    if k in ("empty", "start", "end"):
+    if k == "empty" or k in _LOOKS:
         return True
     if k == "lit":
         return False
@@ -626,6 +657,12 @@ def _byte_classes(nfa: _NFA) -> List[int]:
     """regex-automata ByteClassSet: contiguous byte ranges; a new class starts wherever some byte set of
     the NFA changes membership, so classes[255] is the largest id and alphabet_len = classes[255] + 2."""
     boundary = [False] * 256
+    kinds = {t[1] for t in nfa.st if t[0] == "look"}
+    if kinds & {"sol", "eol"}:
+        boundary[0x0A] = boundary[0x0B] = True
+    if kinds & {"wb", "nwb"}:
+        for b in (0x30, 0x3A, 0x41, 0x5B, 0x5F, 0x60, 0x61, 0x7B):
+            boundary[b] = True
     for t in nfa.st:
         if t[0] == "byte":
             bs = t[1]
@@ -665,12 +702,28 @@ def _determinize(nfa: _NFA, start: int, classes: List[int], *, reverse: bool, le
         nfa.patch(loop, ("split", [start, anyb]))
         un_start = loop
 
-    index: Dict[Tuple[Tuple[int, ...], bool], int] = {}
-    states: List[Tuple[Tuple[int, ...], bool]] = []
-    table: List[List[int]] = []
+    # A DFA state: the NFA set (assertions still pending in it), "the previous position was a match" and — while an
+    # assertion is pending — the context BEHIND the position in scan order (the byte scanned last, or the start configuration)
+    kinds = {t[1] for t in nfa.st if t[0] == "look"}
 
-    def intern(key) -> int:
-        if key == ((), False):
+    def behind(ctx: int, nfa_set: Tuple[int, ...]) -> int:
+        if not any(nfa.st[x][0] == "look" for x in nfa_set):
+            return OTHER
+        if ctx == LF and not kinds & {"sol", "eol"}:
+            ctx = OTHER
+        if ctx == WORD and not kinds & {"wb", "nwb"}:
+            ctx = OTHER
+        return ctx
+
+    Key = Tuple[Tuple[int, ...], bool, int]
+    index: Dict[Key, int] = {}
+    states: List[Key] = []
+    table: List[List[int]] = []
+    dead_key: Key = ((), False, OTHER)
+
+    def intern(nfa_set: Tuple[int, ...], matched: bool, ctx: int) -> int:
+        key = (nfa_set, matched, behind(ctx, nfa_set))
+        if key == dead_key:
             return DEAD
         if key not in index:
             index[key] = len(states)
@@ -678,34 +731,31 @@ def _determinize(nfa: _NFA, start: int, classes: List[int], *, reverse: bool, le
             table.append([DEAD] * alphabet_len)
         return index[key]
 
-    states.append(((), False)); table.append([DEAD] * alphabet_len)   # state 0 = dead
-    index[((), False)] = 0
+    states.append(dead_key); table.append([DEAD] * alphabet_len)   # state 0 = dead
+    index[dead_key] = 0
 
-    def start_state(seed: int, text: bool) -> int:
-        # forward: Start::Text satisfies ^ ; reverse: Start::Text means "at the end of the haystack" and satisfies $
-        clo = _closure(nfa, [seed], look_start=(text and not reverse), look_end=(text and reverse))
-        return intern((clo, False))
-
+    # Start::{NonWordByte, WordByte, Text, LineLF, LineCR, CustomLineTerminator}: what lies behind the search start
+    START_CTX = (OTHER, WORD, EDGE, LF, OTHER, OTHER)
     starts = []
     for seed in ([un_start] if want_unanchored else [None]) + [start]:
         for cfg in range(6):
             if seed is None:
                 starts.append(DEAD)
             else:
-                starts.append(start_state(seed, cfg == 2))
+                starts.append(intern(_closure(nfa, [seed]), False, START_CTX[cfg]))
 
     done = 0
     while done < len(states):
-        nfa_set, _flag = states[done]
+        nfa_set, _flag, back = states[done]
         si = done
         done += 1
         if si == DEAD:
             continue
 
-        def step(byte: Optional[int]) -> Tuple[Tuple[int, ...], bool]:
-            cur = nfa_set
-            if byte is None:   # EOI: the haystack edge satisfies $ going forward, ^ going backward
-                cur = _closure(nfa, list(cur), look_start=reverse, look_end=not reverse)
+        def step(byte: Optional[int]) -> int:
+            ahead = _ctx(byte)
+            # the position between `back` and `ahead`: both sides known now (reverse scan: `back` is on the right)
+            cur = _closure(nfa, list(nfa_set), (ahead, back) if reverse else (back, ahead))
             nxt: List[int] = []
             matched = False
             for s in cur:
@@ -716,13 +766,13 @@ def _determinize(nfa: _NFA, start: int, classes: List[int], *, reverse: bool, le
                         break          # lower-priority threads are cut
                 elif t[0] == "byte" and byte is not None and byte in t[1]:
                     nxt.append(t[2])
-            clo = _closure(nfa, nxt, False, False) if nxt else ()
-            return (clo, matched)
+            clo = _closure(nfa, nxt) if nxt else ()
+            return intern(clo, matched, ahead)
 
         for c in range(ncls):
-            table[si][c] = intern(step(rep_byte[c]))
-        table[si][alphabet_len - 1] = intern(step(None))
-    return _Built(table, [f for (_s, f) in states], starts, classes, alphabet_len)
+            table[si][c] = step(rep_byte[c])
+        table[si][alphabet_len - 1] = step(None)
+    return _Built(table, [f for (_s, f, _c) in states], starts, classes, alphabet_len)
 
 
 def _serialize(b: _Built, *, start_kind: int, has_empty: bool, is_utf8: bool, always_anchored: bool) -> bytes:
