@@ -311,10 +311,13 @@ __device__ __forceinline__ void emit_header(Out& out, const Str& key, const Str&
 }
 
 // ------------------------------------------------------------------ LDS image of one wave
+constexpr uint32_t SEG_CAP = 40;       // tag-specs the lane-per-tag parse looks at: ZKE_MAX_TAGS + 1 decide everything
+static_assert(SEG_CAP > ZKE_MAX_TAGS && SEG_CAP <= 64, "one lane per tag-spec");
 struct ParseLds {
   uint32_t hdr[4 * HDR_LDS_ENTRIES];   // key_start, key_end, val_start, val_end of headers 0..127 (hdr_get / hdr_put)
   uint32_t tag[TG_N][4];               // raw_s, raw_e, val_off, val_len (last occurrence wins, as IndexMap::insert)
   uint8_t tagbuf[ZKE_MAX_TAGBUF];      // FWS-stripped tag values
+  uint16_t seg[5][SEG_CAP];            // lane-per-tag parse: position of the k-th ';', and of tag-spec k: raw_s, raw_e, val_off, val_end
   __attribute__((aligned(16))) uint8_t stage[PARSE_STAGE_BYTES];   // head of the e-mail (header block), copied in 16-byte lanes
 };
 
@@ -405,11 +408,13 @@ __device__ __forceinline__ uint32_t parse_tag_spec(ParseLds& L, const Str& v, Wi
   return rend;
 }
 
-// cfdkim validate_header over the header value v.  0 = valid, else ZKE_D_*
-__device__ __forceinline__ uint32_t validate_sig(ParseLds& L, const Str& v, uint32_t& present) {
+// The tag list, serially: one tag-spec after the other, each scan 64 bytes wide (the later signature rounds inside the
+// verdict launch, and whatever the lane-per-tag parse below hands back).  0, ZKE_D_SIG_SYNTAX or ZKE_D_U_*
+__device__ __forceinline__ uint32_t taglist_serial(ParseLds& L, const Str& v, uint32_t& present) {
   Win w; w.wpos = WNONE; w.c = 0;
   uint32_t ntags = 0, tb = 0, err = 0;
   present = 0;
+  if (wfind(v, w, 0, v.len, [](uint32_t c) { return c >= 0x80 && c != OOB; }) < v.len) return ZKE_D_U_SIG_NON_ASCII;
   uint32_t p = parse_tag_spec(L, v, w, 0, present, ntags, tb, err);
   if (p == NONE) return ZKE_D_SIG_SYNTAX;
   while (!err && p < v.len && at(v, w, p) == ';') {
@@ -417,6 +422,151 @@ __device__ __forceinline__ uint32_t validate_sig(ParseLds& L, const Str& v, uint
     if (q == NONE) break;
     p = q;
   }
+  return err;
+}
+
+__device__ __forceinline__ uint32_t lanes_below(uint64_t m) {     // set bits of m in the lanes below this one
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+constexpr uint32_t TL_SERIAL = 0xFFFFFFF0u;      // "take taglist_serial"
+
+// The tag list, one LANE per tag-spec.  A tag value holds no ';' (valchar excludes it), a name and FWS do not either,
+// so the tag-specs are exactly the ';'-separated pieces of v — up to the first byte that is neither valchar, FWS nor
+// ';': the value it sits in ends there and nothing behind it is parsed (parse_tag_list stops silently), which is the
+// parse of v cut off at that byte.  Three steps:
+//   1. 64 bytes of v per step: the ';' write their positions into seg[0] by rank; first bad byte; any byte >= 0x80;
+//   2. lane k walks the head of piece k ([FWS] name [FWS] "=" [FWS]) and its tail (FWS in front of the ';') byte by
+//      byte — a handful of bytes each, all pieces at once; the first piece that is no tag-spec ends the list;
+//   3. 64 bytes per step again: a byte looks its piece up by the number of ';' in front of it and is kept when it lies
+//      in the piece's value and is not FWS (compaction into tagbuf); the bytes at raw_s / raw_e - 1 note where the
+//      stripped value begins and ends.
+// A piece whose head or tail needs more than WALK_BUDGET steps (long runs of FWS, long names) hands the whole list to
+// taglist_serial, as does a value of 64 KB or more.
+constexpr uint32_t WALK_BUDGET = 40;
+__device__ __forceinline__ uint32_t taglist_lanes(ParseLds& L, const Str& v, uint32_t& present) {
+  const uint32_t lane = (uint32_t)lane_id();
+  const uint32_t n = v.len;
+  present = 0;
+  if (n > 0xFFFFu) return TL_SERIAL;
+  // ---- 1
+  uint32_t nsemi = 0, neff = n;
+  for (uint32_t base = 0; base < n; base += 64) {
+    const uint32_t p = base + lane;
+    const uint32_t c = ldb(v, p);                       // OOB behind the end
+    if (__ballot(p < n && c >= 0x80)) return ZKE_D_U_SIG_NON_ASCII;
+    if (base < neff) {
+      const bool semi = c == ';';
+      const uint64_t bm = __ballot(p < n && !(is_valchar(c) || is_fws(c) || semi));
+      const uint32_t lim = bm ? (uint32_t)__builtin_ctzll(bm) : 64u;
+      const uint64_t sm = __ballot(semi) & bits_below(lim);
+      const uint32_t rank = nsemi + lanes_below(sm);
+      if (semi && lane < lim && rank < SEG_CAP) L.seg[0][rank] = (uint16_t)p;
+      nsemi += (uint32_t)__builtin_popcountll(sm);
+      if (bm) neff = base + lim;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // ---- 2
+  const uint32_t nseg = nsemi + 1 < SEG_CAP ? nsemi + 1 : SEG_CAP;
+  const bool active = lane < nseg;
+  uint32_t s = 0, e = neff;
+  if (active) {
+    if (lane > 0) s = (uint32_t)L.seg[0][lane - 1] + 1u;
+    if (lane < nsemi) e = (uint32_t)L.seg[0][lane];
+  }
+  uint32_t budget = active ? WALK_BUDGET : 0u;
+  uint32_t p = s, c = OOB;
+  auto walk = [&](auto pred) {        // p: first position in [p, e) whose byte fails pred; c: that byte (OOB at e)
+    for (;;) {
+      c = (p < e && budget) ? ldb(v, p) : OOB;
+      if (c == OOB || !pred(c)) break;
+      p++; budget--;
+    }
+  };
+  bool ok = active;
+  walk([](uint32_t x) { return is_fws(x); });
+  ok = ok && is_alpha(c);
+  const uint32_t ns = p, c0 = c;
+  if (ok) { p++; walk([](uint32_t x) { return is_alnumpunc(x); }); }
+  const uint32_t nl = p - ns;
+  uint32_t c1 = 0;
+  if (ok && nl == 2) c1 = ldb(v, ns + 1);
+  if (ok) walk([](uint32_t x) { return is_fws(x); });
+  ok = ok && c == '=';
+  if (ok) { p++; walk([](uint32_t x) { return is_fws(x); }); }
+  const uint32_t rs = p;
+  uint32_t re = e;
+  if (ok) {
+    for (;;) {                         // everything in [rs, e) is valchar or FWS: the last valchar is the last non-FWS
+      if (!(re > rs && budget)) break;
+      if (!is_fws(ldb(v, re - 1))) break;
+      re--; budget--;
+    }
+  }
+  if (__ballot(active && budget == 0)) return TL_SERIAL;
+  const uint64_t nm = __ballot(active && !ok);
+  const uint32_t T = nm ? (uint32_t)__builtin_ctzll(nm) : nseg;
+  if (T == 0) return ZKE_D_SIG_SYNTAX;
+  const uint32_t Tcap = T < ZKE_MAX_TAGS ? T : ZKE_MAX_TAGS;
+  const bool mine = lane < Tcap;
+  // the name (case-sensitive, exact); the last tag of a name wins (IndexMap::insert)
+  int id = -1;
+  if (mine && nl == 1) {
+    switch (c0) {
+      case 'v': id = TG_V; break; case 'a': id = TG_A; break; case 'b': id = TG_B; break; case 'd': id = TG_D; break;
+      case 'h': id = TG_H; break; case 's': id = TG_S; break; case 'i': id = TG_I; break; case 'q': id = TG_Q; break;
+      case 'c': id = TG_C; break; case 'l': id = TG_L; break; default: break;
+    }
+  } else if (mine && nl == 2 && c0 == 'b' && c1 == 'h') {
+    id = TG_BH;
+  }
+  bool winner = false;
+#pragma unroll
+  for (int x = 0; x < TG_N; x++) {
+    const uint64_t m = __ballot(id == x);
+    if (m) { present |= 1u << x; winner = winner || (id == x && lane == 63u - (uint32_t)__builtin_clzll(m)); }
+  }
+  if (mine) { L.seg[1][lane] = (uint16_t)rs; L.seg[2][lane] = (uint16_t)(re > rs ? re : rs); L.seg[3][lane] = 0; L.seg[4][lane] = 0; }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // ---- 3
+  uint32_t tb = 0, before = 0;         // bytes kept, ';' passed
+  for (uint32_t base = 0; base < neff && before < Tcap; base += 64) {
+    const uint32_t q = base + lane;
+    const uint32_t b = q < neff ? ldb(v, q) : OOB;
+    const uint64_t sm = __ballot(b == ';');
+    const uint32_t k = before + lanes_below(sm);
+    before += (uint32_t)__builtin_popcountll(sm);
+    uint32_t vs = 0, ve = 0;
+    if (k < Tcap) { vs = L.seg[1][k]; ve = L.seg[2][k]; }
+    const bool keep = q >= vs && q < ve && !is_fws(b);
+    const uint64_t km = __ballot(keep);
+    const uint32_t d = tb + lanes_below(km);
+    if (keep && d < ZKE_MAX_TAGBUF) {
+      L.tagbuf[d] = (uint8_t)b;
+      if (q == vs) L.seg[3][k] = (uint16_t)d;
+      if (q + 1 == ve) L.seg[4][k] = (uint16_t)(d + 1);
+    }
+    tb += (uint32_t)__builtin_popcountll(km);
+  }
+  if (tb > ZKE_MAX_TAGBUF) return ZKE_D_U_SIG_TOO_LONG;
+  if (T > ZKE_MAX_TAGS) return ZKE_D_U_TOO_MANY_TAGS;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (winner) {
+    const uint32_t off = L.seg[3][lane], end = L.seg[4][lane];
+    L.tag[id][0] = rs; L.tag[id][1] = re > rs ? re : rs; L.tag[id][2] = off; L.tag[id][3] = end - off;
+  }
+  return 0;
+}
+
+// cfdkim validate_header over the header value v.  0 = valid, else ZKE_D_* (ZKE_D_U_SIG_NON_ASCII: a byte >= 0x80 —
+// from_utf8_lossy would rewrite it — is reported, never guessed)
+template <bool FAST>
+__device__ __forceinline__ uint32_t validate_sig(ParseLds& L, const Str& v, uint32_t& present) {
+  uint32_t err = FAST ? taglist_lanes(L, v, present) : TL_SERIAL;
+  if (err == TL_SERIAL) err = taglist_serial(L, v, present);
   if (err) return err;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -1006,19 +1156,10 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
     if (A.mode == 1 && hx != first_sig_hdr) break;
     const Str v = substr(raw, vs, ve);
     auto note_err = [&](uint32_t e) { err_all = e; if (have_cand) err_after = e; last_touched = this_ix; };
-    // from_utf8_lossy would rewrite invalid UTF-8: any byte >= 0x80 is reported, never guessed
-    {
-      Win w; w.wpos = WNONE; w.c = 0;
-      if (wfind(v, w, 0, v.len, [](uint32_t c) { return c >= 0x80 && c != OOB; }) < v.len) {
-        unsupported = ZKE_D_U_SIG_NON_ASCII; last_touched = this_ix;
-        if (A.mode == 1) { finish(ZKE_UNSUPPORTED, unsupported); return; }
-        continue;
-      }
-    }
     uint32_t present;
-    const uint32_t verr = validate_sig(L, v, present);
+    const uint32_t verr = validate_sig<FAST>(L, v, present);
     if (A.debug_stop == 5) return;
-    if (verr == ZKE_D_U_TOO_MANY_TAGS || verr == ZKE_D_U_SIG_TOO_LONG) {
+    if (verr == ZKE_D_U_SIG_NON_ASCII || verr == ZKE_D_U_TOO_MANY_TAGS || verr == ZKE_D_U_SIG_TOO_LONG) {
       unsupported = verr; last_touched = this_ix;
       if (A.mode == 1) { finish(ZKE_UNSUPPORTED, verr); return; }
       continue;
