@@ -83,22 +83,48 @@ def qnorm(W, G, cross):
     return out
 
 
+def cond_sub(acc, nn, G):
+    """The last step of rsa_group_wave: acc (exact limbs, < 2n) minus n when acc >= n.  Per lane the sign of the highest
+    differing limb; the highest differing lane of the group decides acc >= n, the lanes below a lane decide its borrow."""
+    c = []
+    for p in range(G):
+        d = 0
+        for j in reversed(range(QL)):
+            if d == 0:
+                d = (acc[p][j] > nn[p][j]) - (acc[p][j] < nn[p][j])
+        c.append(d)
+    gt = sum(1 << p for p in range(G) if c[p] > 0)
+    lt = sum(1 << p for p in range(G) if c[p] < 0)
+    if gt < lt:
+        return acc
+    out = []
+    for p in range(G):
+        low = (1 << p) - 1
+        borrow = 1 if (lt & low) > (gt & low) else 0
+        lane = []
+        for j in range(QL):
+            t = acc[p][j] - nn[p][j] - borrow
+            lane.append(t & MASK)
+            borrow = 1 if t < 0 else 0
+        out.append(lane)
+    return out
+
+
 def group_modexp(s, n, G):
     Rbits = 28 * QL * G
     rr = to_lanes(pow(2, 2 * Rbits, n), G)
     ninv = (-pow(n, -1, 1 << 28)) & MASK
     nn = to_lanes(n, G)
     acc = to_lanes(s, G)
-    xm = None
+    plain = acc
+    # s R, sixteen squarings -> s^65536 R; the last product takes the PLAIN s: (s^65536 R) s / R = s^65537, out of the
+    # Montgomery domain without a product by one
     for step in range(18):
-        b = rr if step == 0 else (xm if step == 17 else acc)
-        acc = qnorm(qmont_columns(acc, b, nn, ninv, G), G, 1)
+        b = rr if step == 0 else (plain if step == 17 else acc)
+        acc = qnorm(qmont_columns(acc, b, nn, ninv, G), G, G - 1 if step == 17 else 1)
         assert from_lanes(acc) < 2 * n                               # no conditional subtraction: values stay below 2n
-        if step == 0:
-            xm = acc
-    one = to_lanes(1, G)
-    em = qnorm(qmont_columns(acc, one, nn, ninv, G), G, G - 1)
-    assert all(l <= MASK for lane in em for l in lane)               # exact limbs
+    assert all(l <= MASK for lane in acc for l in lane)              # exact limbs
+    em = cond_sub(acc, nn, G)                                        # < n + n^2 / R: one subtraction at most
     return from_lanes(em)
 
 
@@ -122,6 +148,20 @@ def test_group_modexp_worst_case_limbs(G, bits):
         assert group_modexp(s, n, G) == pow(s, 65537, n), (G, hex(s)[:20])
     n = (1 << (bits - 1)) + 1                                        # the smallest modulus of this length
     assert group_modexp(n - 1, n, G) == pow(n - 1, 65537, n)
+
+
+@pytest.mark.parametrize("G,bits", [(4, 2048), (4, 1031), (8, 4096), (8, 2100)])
+def test_conditional_subtraction(G, bits):
+    """The kernel's last step on values a signature that verifies never produces (acc >= n): equal, one more, all borrows
+    (n with zero low limbs), the largest value the last product can leave."""
+    rng = random.Random(31 * G + bits)
+    ns = [rand_odd(bits, rng), (1 << (bits - 1)) + 1, (1 << bits) - 1, (1 << (bits - 1)) + (1 << (28 * QL)) + 1]
+    for n in ns:
+        for x in (0, 1, n - 1, n, n + 1, n + (1 << (28 * QL)) - 1, n + (n >> 80), 2 * n - 1, rng.randrange(n), n + rng.randrange(n)):
+            if x >= 1 << (28 * QL * G):
+                continue
+            got = from_lanes(cond_sub(to_lanes(x, G), to_lanes(n, G), G))
+            assert got == (x - n if x >= n else x), (G, bits, hex(x)[:18])
 
 
 @pytest.mark.parametrize("NL,G", [(1, 4), (2, 8)])

@@ -189,7 +189,14 @@ Slot* new_slot(zke_engine* e) {
     for (int k = 0; k < atoi(xd); k++) { hipStream_t d; (void)hipStreamCreateWithFlags(&d, hipStreamNonBlocking); }
   }
   const char* sp = getenv("ZKE_STREAM_PRIO");     // experiment: create the slot streams with an explicit priority
-  bool ok = (sp ? hipStreamCreateWithPriority(&w->stream, hipStreamNonBlocking, atoi(sp)) : hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking)) == hipSuccess &&
+  if (const char* xm = getenv("ZKE_X_CU_MASK")) {              // experiment: a slot's launches on 32 of the 256 CUs (1: bits k, k+8, ...; 2: bits 32k .. 32k+31)
+    static int slot_ix = 0;
+    const int k = slot_ix++ % 8, mode = atoi(xm);
+    uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b = 0; b < 256; b++) if (mode == 1 ? (b % 8 == k) : (b / 32 == k)) mask[b / 32] |= 1u << (b % 32);
+    if (hipExtStreamCreateWithCUMask(&w->stream, 8, mask) != hipSuccess) { e->err = "hipExtStreamCreateWithCUMask"; delete w; return nullptr; }
+  }
+  bool ok = (w->stream ? hipSuccess : sp ? hipStreamCreateWithPriority(&w->stream, hipStreamNonBlocking, atoi(sp)) : hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking)) == hipSuccess &&
             hipEventCreateWithFlags(&w->done, hipEventDisableTiming) == hipSuccess;
   for (auto& ev : w->ev) ok = ok && hipEventCreate(&ev) == hipSuccess;
   if (!ok) { e->err = "slot stream / event creation"; delete w; return nullptr; }

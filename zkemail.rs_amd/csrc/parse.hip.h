@@ -152,6 +152,13 @@ __device__ __forceinline__ uint32_t at(const Str& s, Win& w, uint32_t pos) {   /
   if (pos - w.wpos >= 64u) wload(s, w, pos);
   return __builtin_amdgcn_readlane(w.c, pos - w.wpos);
 }
+// A value every lane holds alike (loaded from LDS or memory at a wave-uniform address), as a scalar: branches on it are
+// then scalar branches, not exec-mask regions — the parser's control flow is wave-uniform, but the compiler can only see
+// that where the values come out of v_readfirstlane / v_readlane.
+__device__ __forceinline__ uint32_t uni(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ uint32_t lanes_below(uint64_t m) {     // set bits of m in the lanes below this one
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
 __device__ __forceinline__ uint64_t bits_from(uint32_t rel) { return rel >= 64 ? 0ull : (~0ull << rel); }
 __device__ __forceinline__ uint64_t bits_below(uint32_t rel) { return rel >= 64 ? ~0ull : ((1ull << rel) - 1); }
 
@@ -257,7 +264,7 @@ __device__ __forceinline__ void emit_relaxed_value(Out& out, const Str& v) {
   const uint32_t L = v.len;
   if (L == 0) return;
   const int lane = lane_id();
-  bool prev_wsp = false;       // the last kept byte before this chunk is WSP
+  uint64_t cin = 0;            // a kept WSP byte lies behind the last kept non-WSP byte in front of this chunk
   bool started = false;        // a non-WSP byte has been emitted
   uint32_t prev_last = OOB;    // raw byte in front of this chunk
   uint32_t cur = ldb(v, (uint32_t)lane);
@@ -267,26 +274,27 @@ __device__ __forceinline__ void emit_relaxed_value(Out& out, const Str& v) {
     uint32_t cp = lane_shr1(cur); if (lane == 0) cp = prev_last;
     const uint32_t nfirst = __builtin_amdgcn_readfirstlane(nxt);     // outside the lane test: all lanes active here
     uint32_t cn = lane_shl1(cur); if (lane == 63) cn = nfirst;
-    const bool inr = l < L;
     const bool crlf = (cur == '\r' && cn == '\n') || (cur == '\n' && cp == '\r');
-    const bool kept = inr && !crlf;
+    const bool kept = l < L && !crlf;
     const bool wsp = is_wsp(cur);
     const bool nw = kept && !wsp;
-    const uint64_t K = __ballot(kept), W = __ballot(kept && wsp), N = __ballot(nw);
-    const uint64_t below = bits_below(lane);
-    bool prevw = prev_wsp;
-    const uint64_t lowerK = K & below;
-    if (lowerK) prevw = (W >> (63 - __builtin_clzll(lowerK))) & 1;
-    const bool sp = nw && prevw && (started || (N & below) != 0);
-    const uint64_t S = __ballot(sp);
+    const uint64_t W = __ballot(kept && wsp), N = __ballot(nw);
+    // "a kept WSP lies between byte i and the last kept non-WSP byte below it" is a carry chain over the chunk — a WSP byte
+    // generates, a dropped byte (CRLF, beyond the end) propagates, a non-WSP byte kills — solved for all 64 bytes by ONE
+    // 64-bit addition on the scalar unit (a = generate | propagate, b = generate: the carry INTO bit i is sum ^ a ^ b).
+    const uint64_t a = ~N, b = W;
+    const uint64_t sum = a + b + cin;
+    const uint64_t C = sum ^ a ^ b;
+    uint64_t S = N & C;                                            // non-WSP bytes that get the run's single SP in front
+    if (!started) S &= ~(N & (0 - N));                             // ... except the first one of the value: leading WSP vanishes
+    cin = ((a & b) | ((a | b) & ~sum)) >> 63;                      // the carry out of bit 63
     const uint32_t cnt = (uint32_t)__builtin_popcountll(N) + (uint32_t)__builtin_popcountll(S);
     if (out.o + cnt > out.cap) { out.overflow = true; return; }
     if (nw) {
-      uint8_t* dst = out.p + out.o + (uint32_t)__builtin_popcountll(N & below) + (uint32_t)__builtin_popcountll(S & below);
-      if (sp) { dst[0] = (uint8_t)' '; dst[1] = (uint8_t)cur; } else dst[0] = (uint8_t)cur;
+      uint8_t* dst = out.p + out.o + lanes_below(N) + lanes_below(S);
+      if ((S >> lane) & 1) { dst[0] = (uint8_t)' '; dst[1] = (uint8_t)cur; } else dst[0] = (uint8_t)cur;
     }
     out.o += cnt;
-    if (K) prev_wsp = (W >> (63 - __builtin_clzll(K))) & 1;
     started = started || N != 0;
     prev_last = __builtin_amdgcn_readlane(cur, 63);
     cur = nxt;
@@ -296,11 +304,21 @@ __device__ __forceinline__ void emit_relaxed_value(Out& out, const Str& v) {
 // cfdkim canonicalize_header_{relaxed,simple}(key, value); the CRLF is appended by the caller's choice
 __device__ __forceinline__ void emit_header(Out& out, const Str& key, const Str& val, bool relaxed, bool crlf) {
   if (relaxed) {
-    Win w; w.wpos = WNONE; w.c = 0;
-    uint32_t ke = wrfind(key, w, 0, key.len, [](uint32_t c) { return !is_wsp(c); });
-    ke = (ke == NONE) ? 0 : ke + 1;
-    emit_map(out, key, 0, ke, [](uint32_t c) { return lower(c); });
-    emit_lit(out, LIT(":"));
+    uint32_t ke = key.len;
+    if (ke && is_wsp(uni(ldb(key, ke - 1)))) {            // WSP in front of the ':' (rare): the name ends at its last non-WSP byte
+      Win w; w.wpos = WNONE; w.c = 0;
+      ke = wrfind(key, w, 0, key.len, [](uint32_t c) { return !is_wsp(c); });
+      ke = (ke == NONE) ? 0 : ke + 1;
+    }
+    if (ke < 64) {                                        // the lower-cased name and its ':' as one store
+      if (out.o + ke + 1 > out.cap) { out.overflow = true; return; }
+      const uint32_t l = (uint32_t)lane_id();
+      if (l <= ke) out.p[out.o + l] = l < ke ? (uint8_t)lower(ldb(key, l)) : (uint8_t)':';
+      out.o += ke + 1;
+    } else {
+      emit_map(out, key, 0, ke, [](uint32_t c) { return lower(c); });
+      emit_lit(out, LIT(":"));
+    }
     emit_relaxed_value(out, val);
   } else {
     emit_map(out, key, 0, key.len, [](uint32_t c) { return c; });
@@ -324,10 +342,6 @@ struct ParseLds {
 // Header span table: 64 entries in LDS (10 KB of LDS per wave would cap a CU at 16 front-end waves; 6.7 KB lets the
 // register budget decide: 24), the rest — e-mails with more than 64 header fields — in the e-mail's scratch slot.
 // The overflow is written and read back by the same wave: the reads go around L1 (agent-scope atomic loads).
-// A value every lane holds alike (loaded from LDS or memory at a wave-uniform address), as a scalar: branches on it are
-// then scalar branches, not exec-mask regions — the parser's control flow is wave-uniform, but the compiler can only see
-// that where the values come out of v_readfirstlane / v_readlane.
-__device__ __forceinline__ uint32_t uni(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
 struct HdrSpan { uint32_t ks, ke, vs, ve; };
 __device__ __forceinline__ void hdr_put(ParseLds& L, uint32_t* ovf, uint32_t x, uint32_t ks, uint32_t ke, uint32_t vs, uint32_t ve) {
   if (lane_id() != 0) return;
@@ -425,9 +439,6 @@ __device__ __forceinline__ uint32_t taglist_serial(ParseLds& L, const Str& v, ui
   return err;
 }
 
-__device__ __forceinline__ uint32_t lanes_below(uint64_t m) {     // set bits of m in the lanes below this one
-  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-}
 constexpr uint32_t TL_SERIAL = 0xFFFFFFF0u;      // "take taglist_serial"
 
 // The tag list, one LANE per tag-spec.  A tag value holds no ';' (valchar excludes it), a name and FWS do not either,
@@ -1284,7 +1295,11 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
       const uint32_t hl = tagf(L, TG_H, 3);
       // h= is split at every ':' (FWS is already stripped; empty entries count).  The ':' after position `from`, 64 bytes
       // of the value per step, instead of a scalar walk over its bytes.
+      // (an h= value of at most 64 bytes — five to ten names — has its ':' in ONE mask: no loop, no further reads)
+      const bool one_win = hl <= 64;
+      const uint64_t colons = one_win ? __ballot((uint32_t)lane < hl && h[(uint32_t)lane < hl ? lane : 0] == ':') : 0ull;
       auto colon_after = [&](uint32_t from) -> uint32_t {
+        if (one_win) { const uint64_t m = colons & bits_from(from); return m ? (uint32_t)__builtin_ctzll(m) : hl; }
         for (uint32_t base = from & ~63u; base < hl; base += 64) {
           const uint32_t l = base + (uint32_t)lane;
           const uint64_t m = __ballot(l < hl && l >= from && h[l] == ':');
