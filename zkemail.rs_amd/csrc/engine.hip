@@ -4,6 +4,7 @@
 // verification arithmetic runs on the host and there is no CPU fallback: without a HIP
 // device every entry point returns ZKE_E_DEVICE.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cstddef>
@@ -69,6 +70,7 @@ constexpr uint32_t SHA_PAIR_MAX_GROUPS = 512;      // launches of up to 32 768 m
 // the per-key Montgomery constants (one cache per device) and the registered DFA tables.
 struct Slot {
   hipStream_t stream = nullptr;        // the slot's own stream: batches submitted with stream == NULL run here
+  bool owns_stream = true;
   hipStream_t last_stream = nullptr;   // stream of the slot's previous batch (nullptr: the slot has not been used)
   hipEvent_t done = nullptr;           // recorded behind the slot's last batch; waited for when the stream changes
   hipEvent_t ev[16]{};                 // per-kernel timing marks (zke_set_timing)
@@ -189,6 +191,10 @@ Slot* new_slot(zke_engine* e) {
     for (int k = 0; k < atoi(xd); k++) { hipStream_t d; (void)hipStreamCreateWithFlags(&d, hipStreamNonBlocking); }
   }
   const char* sp = getenv("ZKE_STREAM_PRIO");     // experiment: create the slot streams with an explicit priority
+  if (const char* xs = getenv("ZKE_X_SHARE")) {                // experiment: slot i >= k runs on the stream of slot i - k (two workspaces per hardware queue)
+    const size_t k = (size_t)atoi(xs);
+    if (k && e->slots.size() >= k) { w->stream = e->slots[e->slots.size() - k]->stream; w->owns_stream = false; }
+  }
   if (const char* xm = getenv("ZKE_X_CU_MASK")) {              // experiment: a slot's launches on 32 of the 256 CUs (1: bits k, k+8, ...; 2: bits 32k .. 32k+31)
     static int slot_ix = 0;
     const int k = slot_ix++ % 8, mode = atoi(xm);
@@ -205,12 +211,12 @@ Slot* new_slot(zke_engine* e) {
 }
 void free_slot(Slot* w) {
   if (!w) return;
-  if (w->stream) (void)hipStreamSynchronize(w->stream);
+  if (w->stream && w->owns_stream) (void)hipStreamSynchronize(w->stream);
   if (w->graph_exec) (void)hipGraphExecDestroy(w->graph_exec);
   for (auto* b : w->all) b->release();
   for (auto& ev : w->ev) if (ev) (void)hipEventDestroy(ev);
   if (w->done) (void)hipEventDestroy(w->done);
-  if (w->stream) (void)hipStreamDestroy(w->stream);
+  if (w->stream && w->owns_stream) (void)hipStreamDestroy(w->stream);
   delete w;
 }
 
@@ -394,6 +400,7 @@ int zke_engine_create(const zke_options* opt, zke_engine** out) {
 void zke_engine_destroy(zke_engine* e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
+  for (Slot* w : e->slots) if (w->stream) (void)hipStreamSynchronize(w->stream);      // (slots may share a stream: all drained before any is freed)
   for (Slot* w : e->slots) free_slot(w);
   DevBuf* bufs[] = {&e->in_raw, &e->in_raw_off, &e->in_dom, &e->in_dom_off, &e->in_key, &e->in_key_off, &e->in_ktype,
                     &e->in_extnull, &e->in_cap_off, &e->in_cap_str_off, &e->in_cap_blob, &e->results, &e->misc, &e->key_cache};

@@ -99,7 +99,13 @@ int run_device_pipeline(zke_engine* e, Slot& w, const zke_batch* in, uint64_t ra
     uint32_t* wave_count = w.pending.as<uint32_t>() + 2;
     uint32_t* wave_list = w.rsa_ok.as<uint32_t>();
     ParseArgs pa{B, round, 0, e->debug_parse_stop, e->fuse_canon, e->key_cache.as<KeyCacheEntry>(), route_mask, wave_count, wave_list};
-    hipLaunchKernelGGL(parse_kernel, dim3(n), dim3(64), 0, s, pa);
+    // experiment (ZKE_X_ANYORDER, with ZKE_X_SHARE): the front end without the queue's barrier bit — it reads nothing the slot's
+    // stream has in flight (the other workspace of the pair), so it may start beside the previous batch's verdict launch
+    static const bool x_anyorder = getenv("ZKE_X_ANYORDER") != nullptr;
+    if (x_anyorder && s == w.stream && !e->timing)
+      hipExtLaunchKernelGGL(parse_kernel, dim3(n), dim3(64), 0, s, nullptr, nullptr, hipExtAnyOrderLaunch, pa);
+    else
+      hipLaunchKernelGGL(parse_kernel, dim3(n), dim3(64), 0, s, pa);
     tm.mark();
     if (!e->fuse_canon) {      // the front end canonicalises the body itself
       CanonArgs ca{B, 0};
