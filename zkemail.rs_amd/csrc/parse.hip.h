@@ -735,24 +735,18 @@ __device__ __forceinline__ bool split_headers_lines(ParseLds& L, uint32_t* ovf, 
     const uint64_t Bm = __ballot(c == '\n' && (n1 == '\n' || (n1 == '\r' && n2 == '\n')));
     uint32_t cutbit = 64;
     if (Bm) { cutbit = (uint32_t)__builtin_ctzll(Bm); Lm &= bits_below(cutbit + 1); Cm &= bits_below(cutbit); }
-    const uint64_t below = bits_below(lane);
+    const uint32_t line = n_lines + lanes_below(Lm);             // the line this byte lies in (its LF closes it)
     if ((Lm >> lane) & 1) {
-      const uint32_t r = n_lines + (uint32_t)__builtin_popcountll(Lm & below);
-      if (r < LINE_CAP) lfpos[r] = (uint16_t)l;
-      if (r + 1 < LINE_CAP) colpos[r + 1] = 0xFFFF;
+      if (line < LINE_CAP) lfpos[line] = (uint16_t)l;
+      if (line + 1 < LINE_CAP) colpos[line + 1] = 0xFFFF;
     }
-    if ((Cm >> lane) & 1) {
-      const uint64_t lfb = Lm & below, cb = Cm & below;
-      const bool first = lfb ? (cb >> (64 - (uint32_t)__builtin_clzll(lfb))) == 0 : (cb == 0 && !colon_seen);
-      const uint32_t line = n_lines + (uint32_t)__builtin_popcountll(lfb);
-      if (first && line < LINE_CAP) colpos[line] = (uint16_t)l;
-    }
-    if (Lm) {
-      const uint32_t hl = 63u - (uint32_t)__builtin_clzll(Lm);
-      colon_seen = hl < 63 && (Cm >> (hl + 1)) != 0;
-    } else {
-      colon_seen = colon_seen || Cm != 0;
-    }
+    // "no ':' yet in this line" in front of every byte: a carry chain — an LF generates, a ':' kills, everything else passes
+    // it on — solved by one 64-bit addition (a = generate | propagate = ~Cm, b = generate = Lm; the carry INTO bit i is sum ^ a ^ b)
+    const uint64_t ca = ~Cm, cb = Lm, cin = colon_seen ? 0ull : 1ull;
+    const uint64_t sum = ca + cb + cin;
+    const uint64_t F = Cm & (sum ^ ca ^ cb);                       // the first ':' of each line
+    if (((F >> lane) & 1) && line < LINE_CAP) colpos[line] = (uint16_t)l;
+    colon_seen = (((ca & cb) | ((ca | cb) & ~sum)) >> 63) == 0;    // no carry out: a ':' behind the chunk's last LF
     n_lines += (uint32_t)__builtin_popcountll(Lm);
     if (Bm) { cut = base + cutbit; break; }
   }
