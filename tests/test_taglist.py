@@ -4,6 +4,8 @@ allows: tests/taglist_fuzz.py lays signatures out tag by tag and signs them with
 CPU: the oracle must verify every layout the generator calls "ok" (an expectation that comes from RFC 6376 and the signer,
 not from the oracle).  GPU: the device — one lane per tag-spec (taglist_lanes), the serial parser it falls back to for
 long FWS runs (taglist_serial) — against the oracle, every field of every record."""
+import os
+
 import numpy as np
 import pytest
 
@@ -40,8 +42,12 @@ def test_oracle_verifies_every_layout(oracle, seed):
     assert (A.ZKE_UNSUPPORTED, A.D_U_TOO_MANY_TAGS) in seen and (A.ZKE_DKIM_NOT_PASS, A.D_MISSING_TAG) in seen
 
 
+# ZKE_FUZZ_SEEDS=n widens the sweep to n extra seeds, as for the byte-mutation fuzz in test_gpu_verify.py
+GPU_SEEDS = [1, 2, 3, 4] + list(range(2000, 2000 + int(os.environ.get("ZKE_FUZZ_SEEDS", "0"))))
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+@pytest.mark.parametrize("seed", GPU_SEEDS)
 def test_gpu_taglist_fuzz_parity(engine, oracle, seed):
     from test_gpu_verify import assert_records_equal, run_both
     emails, kinds = make(seed, 1024)
