@@ -260,13 +260,20 @@ __device__ __forceinline__ void emit_map(Out& out, const Str& s, uint32_t a, uin
 // One forward pass, one load per lane and 64-byte chunk (issued a chunk ahead; the neighbours come over DPP):
 // a WSP run becomes the single SP written IN FRONT OF the next kept non-WSP byte, so leading runs (nothing
 // emitted yet) and trailing runs (no such byte) vanish without a backward scan for the last kept byte.
+__device__ __forceinline__ uint64_t uni64(uint64_t x) {
+  return ((uint64_t)uni((uint32_t)(x >> 32)) << 32) | (uint64_t)uni((uint32_t)x);      // (the builtin returns int: widen as unsigned)
+}
 __device__ __forceinline__ void emit_relaxed_value(Out& out, const Str& v) {
   const uint32_t L = v.len;
   if (L == 0) return;
   const int lane = lane_id();
+  // (every loop-carried value below is wave-uniform; said so with v_readfirstlane once per step, or the compiler takes the
+  // loop for a divergent one — counters in vector registers, an exec-mask ledger around every branch)
   uint64_t cin = 0;            // a kept WSP byte lies behind the last kept non-WSP byte in front of this chunk
-  bool started = false;        // a non-WSP byte has been emitted
+  uint32_t started = 0;        // a non-WSP byte has been emitted
   uint32_t prev_last = OOB;    // raw byte in front of this chunk
+  uint32_t o = uni(out.o);
+  const uint32_t cap = uni(out.cap);
   uint32_t cur = ldb(v, (uint32_t)lane);
   for (uint32_t base = 0; base < L; base += 64) {
     const uint32_t nxt = ldb(v, base + 64 + lane);                 // next chunk, in flight during this one
@@ -286,19 +293,21 @@ __device__ __forceinline__ void emit_relaxed_value(Out& out, const Str& v) {
     const uint64_t sum = a + b + cin;
     const uint64_t C = sum ^ a ^ b;
     uint64_t S = N & C;                                            // non-WSP bytes that get the run's single SP in front
-    if (!started) S &= ~(N & (0 - N));                             // ... except the first one of the value: leading WSP vanishes
-    cin = ((a & b) | ((a | b) & ~sum)) >> 63;                      // the carry out of bit 63
-    const uint32_t cnt = (uint32_t)__builtin_popcountll(N) + (uint32_t)__builtin_popcountll(S);
-    if (out.o + cnt > out.cap) { out.overflow = true; return; }
+    S &= started ? ~0ull : ~(N & (0 - N));                         // ... except the first one of the value: leading WSP vanishes
+    S = uni64(S);
+    cin = uni64(((a & b) | ((a | b) & ~sum)) >> 63);               // the carry out of bit 63
+    const uint32_t cnt = uni((uint32_t)__builtin_popcountll(N) + (uint32_t)__builtin_popcountll(S));
+    if (o + cnt > cap) { out.o = o; out.overflow = true; return; }
     if (nw) {
-      uint8_t* dst = out.p + out.o + lanes_below(N) + lanes_below(S);
+      uint8_t* dst = out.p + o + lanes_below(N) + lanes_below(S);
       if ((S >> lane) & 1) { dst[0] = (uint8_t)' '; dst[1] = (uint8_t)cur; } else dst[0] = (uint8_t)cur;
     }
-    out.o += cnt;
-    started = started || N != 0;
+    o = uni(o + cnt);
+    started = uni(started | (N != 0 ? 1u : 0u));
     prev_last = __builtin_amdgcn_readlane(cur, 63);
     cur = nxt;
   }
+  out.o = o;
 }
 
 // cfdkim canonicalize_header_{relaxed,simple}(key, value); the CRLF is appended by the caller's choice
