@@ -50,9 +50,10 @@ def parse_args():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-saturated", action="store_true",
                     help="skip the chip-filling SHA-256 micro-benchmark (profile runs: keeps the kernel stats to the workload's launches)")
-    ap.add_argument("--streams", type=int, default=22,
+    ap.add_argument("--streams", type=int, default=0,
                     help="submission slots of the engine = batches in flight per GPU: step i runs in slot i %% S (a stream and a "
-                         "workspace each; one engine, one key cache); 1 = strictly serial steps")
+                         "workspace each; one engine, one key cache); 1 = strictly serial steps.  Default: 22 on one GPU, 16 when "
+                         "the rank holds an RCCL communicator (N > 1)")
     ap.add_argument("--alone-steps", type=int, default=8,
                     help="steps of the extra pass that runs one batch at a time (per-kernel times of a batch alone); 0 = skip "
                          "(profile runs: every launch in the trace is then an in-flight one)")
@@ -112,12 +113,24 @@ def main():
     args = parse_args()
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args)
+    # stdout carries ONE line, rank 0's JSON: whatever a library prints there (RCCL writes a version banner to stdout when
+    # the communicator comes up) goes to stderr instead
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         args.gpus = world
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # Slots: a stream each, and every stream wants a hardware queue of its own.  The chip schedules a limited number of queues
+    # per process without time-slicing them; past it (48 streams: 0.7 M e-mails/s in the burst) batches wait milliseconds for
+    # their queue's turn.  22 slots + the null stream sit just under the limit on one GPU.  A communicator brings a handful of
+    # streams of its own (RCCL's internal ones, torch's collective stream): with it 20 slots are already over — the 20-step burst
+    # takes 7-50 ms instead of 1.3, the steady state halves — 18 are fine, 16 leave a margin (profiles/r02_dist_queues.txt).
+    will_dist = int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("ZKE_BENCH_FORCE_DIST") == "1"
+    if args.streams <= 0:
+        args.streams = 16 if will_dist else 22
     # HIP multiplexes streams onto 4 hardware queues by default.  Every slot stream needs a queue of its own, and the
     # null stream and the runtime's own queues come out of the same pool: with exactly S queues two slots end up
     # sharing one (measured: 20 slots on 20 queues 18.8 M e-mails/s, on 24 queues 23.1 M; more queues than streams
@@ -140,7 +153,10 @@ def main():
     # ZKE_BENCH_FORCE_DIST=1 exercises the RCCL path (init, all_gather on the step's stream, barrier, all_reduce)
     # even with one rank, so the N > 1 code can be rehearsed on a one-GPU box
     use_dist = world > 1 or os.environ.get("ZKE_BENCH_FORCE_DIST") == "1"
-    if use_dist:
+    # The communicator comes up AFTER the engine (below): the slots' streams get their hardware queues first, RCCL's own
+    # handful of streams take what is left.  See --streams for why a rank with a communicator runs fewer slots.
+
+    def init_pg():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -178,6 +194,8 @@ def main():
     n = packed.n
     P = (packed.nh + packed.nb) if regex_inputs is not None else 0
     eng.reserve(n, totals[0], S, P)
+    if use_dist:
+        init_pg()
     # Result records.  One GPU: a slice per batch in flight.  N > 1: every timed step keeps its records (one slice per
     # step) and the ranks exchange them with ONE all-gather at the end of the timed region — SURVEY §8(e): "one exchange
     # step at the end".  (Measured alternatives on this box, forced through RCCL at N = 1: an all-gather inside every
@@ -237,20 +255,28 @@ def main():
     for _ in range(args.warmup):
         step()
     if use_dist:
-        eng.sync()
-        torch.cuda.synchronize()
+        torch.cuda.synchronize()                      # device-wide: the slots' streams too
         exchange()                                    # untimed: first use of the copy kernels and of the communicator's all-gather
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     t_submitted = time.perf_counter() - t0            # the host side of the timed region: K submissions
+    tail = [] if os.environ.get("ZKE_BENCH_TAIL_TIMES") == "1" else None      # diagnosis: where the end of the region goes
     if use_dist:
-        eng.sync()                                    # every batch of this rank is done
-        torch.cuda.synchronize()
+        torch.cuda.synchronize()                      # every batch of this rank is done (device-wide wait)
+        if tail is not None:
+            tail.append(("drained", time.perf_counter() - t0))
         exchange()
+        if tail is not None:
+            tail.append(("exchange enqueued", time.perf_counter() - t0))
+            torch.cuda.synchronize()
+            tail.append(("exchange done", time.perf_counter() - t0))
     fence()
     dt = time.perf_counter() - t0
+    if tail is not None:
+        tail.append(("fence done", dt))
+        sys.stderr.write("tail_times_ms " + " | ".join(f"{k} {v * 1e3:.3f}" for k, v in tail) + "\n")
     gc.enable()
     if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -418,7 +444,8 @@ def main():
         }
         out["gpu_over_cpu"] = round(emails_per_s / allc, 2)
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()
 

@@ -15,8 +15,8 @@ def test_bench_json_contract():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "60", "--warmup", "10",
                         "--cpu-seconds", "1", "--no-saturated"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]          # ONE line on stdout, the JSON
     j = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -50,5 +50,7 @@ def test_bench_exchange_path_through_rccl_on_one_gpu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "120", "--warmup", "10",
                         "--no-cpu", "--no-saturated"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
-    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]          # RCCL's version banner must not land on stdout
+    j = json.loads(lines[0])
     assert j["n_gpus"] == 1 and "all_gather" in j["config"]["collective"] and j["value"] > 1e5

@@ -1409,11 +1409,33 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
 #ifndef ZKE_PARSE_WAVES
 #define ZKE_PARSE_WAVES 6        // waves per SIMD the front end is compiled for (LDS allows 23 per CU)
 #endif
-__global__ __launch_bounds__(64, ZKE_PARSE_WAVES) void parse_kernel(ParseArgs A) {
-  __shared__ ParseLds L;
-  if (blockIdx.x >= A.b.n) return;
+// ZKE_PARSE_WG_WAVES = W: W e-mails per workgroup, still one per wavefront and nothing shared between them (no barrier,
+// an LDS area each).  W only sets the granularity at which the chip hands out LDS and registers to the front end: with
+// W = 8 a CU holds two workgroups (2 x 8 x 7.2 KB of LDS), i.e. four 80-register waves per SIMD, and 192 registers per SIMD
+// + 44 KB of LDS are always left for the hash / modexp launches of earlier batches (fused.hip.h: 187 registers, 14.6 KB).
+#ifndef ZKE_PARSE_WG_WAVES
+#define ZKE_PARSE_WG_WAVES 1
+#endif
+constexpr size_t PARSE_DYN_LDS = ZKE_PARSE_WG_WAVES > 1 ? ZKE_PARSE_WG_WAVES * sizeof(ParseLds) : 0;     // launch argument
+#ifdef ZKE_PARSE_NUM_VGPR      // with W > 1 the compiler sees an LDS-bound occupancy and takes more registers; this holds them
+#define ZKE_PARSE_VGPR_ATTR __attribute__((amdgpu_num_vgpr(ZKE_PARSE_NUM_VGPR)))
+#else
+#define ZKE_PARSE_VGPR_ATTR
+#endif
+__global__ __launch_bounds__(64 * ZKE_PARSE_WG_WAVES, ZKE_PARSE_WAVES) ZKE_PARSE_VGPR_ATTR void parse_kernel(ParseArgs A) {
+#if ZKE_PARSE_WG_WAVES > 1
+  // dynamic LDS (W * sizeof(ParseLds), given at launch): with the size in sight the compiler takes the kernel's occupancy
+  // for LDS-bound at 4 waves per SIMD and spends 109 registers — the point of W is that the front end stays at 80
+  extern __shared__ __attribute__((aligned(16))) uint8_t parse_lds_raw[];
+  ParseLds* L = reinterpret_cast<ParseLds*>(parse_lds_raw);
+#else
+  __shared__ ParseLds L[1];
+#endif
+  const uint32_t wave = ZKE_PARSE_WG_WAVES > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
+  const uint32_t email = blockIdx.x * ZKE_PARSE_WG_WAVES + wave;
+  if (email >= A.b.n) return;
   if (ZKE_PARSE_PRIO) __builtin_amdgcn_s_setprio(ZKE_PARSE_PRIO);
-  parse_email(A, blockIdx.x, L);
+  parse_email(A, email, L[wave]);
 }
 
 // CSR (blob, off[n+1]) -> ShaJob list with digests packed 32 B apart (building-block entry point)

@@ -103,9 +103,9 @@ int run_device_pipeline(zke_engine* e, Slot& w, const zke_batch* in, uint64_t ra
     // stream has in flight (the other workspace of the pair), so it may start beside the previous batch's verdict launch
     static const bool x_anyorder = getenv("ZKE_X_ANYORDER") != nullptr;
     if (x_anyorder && s == w.stream && !e->timing)
-      hipExtLaunchKernelGGL(parse_kernel, dim3(n), dim3(64), 0, s, nullptr, nullptr, hipExtAnyOrderLaunch, pa);
+      hipExtLaunchKernelGGL(parse_kernel, dim3((n + ZKE_PARSE_WG_WAVES - 1) / ZKE_PARSE_WG_WAVES), dim3(64 * ZKE_PARSE_WG_WAVES), PARSE_DYN_LDS, s, nullptr, nullptr, hipExtAnyOrderLaunch, pa);
     else
-      hipLaunchKernelGGL(parse_kernel, dim3(n), dim3(64), 0, s, pa);
+      hipLaunchKernelGGL(parse_kernel, dim3((n + ZKE_PARSE_WG_WAVES - 1) / ZKE_PARSE_WG_WAVES), dim3(64 * ZKE_PARSE_WG_WAVES), PARSE_DYN_LDS, s, pa);
     tm.mark();
     if (!e->fuse_canon) {      // the front end canonicalises the body itself
       CanonArgs ca{B, 0};
@@ -133,7 +133,7 @@ int run_device_pipeline(zke_engine* e, Slot& w, const zke_batch* in, uint64_t ra
     B2.scratch = w.scratch2.as<uint8_t>();
     B2.meta_verify = B.meta;
     ParseArgs pa{B2, 0, 1, 0, 0, nullptr, 0, nullptr, nullptr};
-    hipLaunchKernelGGL(parse_kernel, dim3(n), dim3(64), 0, s, pa);
+    hipLaunchKernelGGL(parse_kernel, dim3((n + ZKE_PARSE_WG_WAVES - 1) / ZKE_PARSE_WG_WAVES), dim3(64 * ZKE_PARSE_WG_WAVES), PARSE_DYN_LDS, s, pa);
     CanonArgs ca{B2, 1};
     hipLaunchKernelGGL(canon_body_kernel, dim3(n), dim3(64), 0, s, ca);
     QpArgs qa{B2, B.meta, w.clean.as<uint8_t>(), clean_off, B.scratch, B.scratch_off};
