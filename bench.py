@@ -60,6 +60,11 @@ def parse_args():
     return ap.parse_args()
 
 
+def default_slots(with_communicator: bool) -> int:
+    """Submission slots per GPU when --streams is not given: 22 alone, 16 beside an RCCL communicator (main() says why)."""
+    return 16 if with_communicator else 22
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start N ranks as children (torch.distributed.run) and pass rank 0's
     JSON line through.  The parent has not touched the GPU — nothing is exec'ed from a process that initialised HIP."""
@@ -130,7 +135,7 @@ def main():
     # takes 7-50 ms instead of 1.3, the steady state halves — 18 are fine, 16 leave a margin (profiles/r02_dist_queues.txt).
     will_dist = int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("ZKE_BENCH_FORCE_DIST") == "1"
     if args.streams <= 0:
-        args.streams = 16 if will_dist else 22
+        args.streams = default_slots(will_dist)
     # HIP multiplexes streams onto 4 hardware queues by default.  Every slot stream needs a queue of its own, and the
     # null stream and the runtime's own queues come out of the same pool: with exactly S queues two slots end up
     # sharing one (measured: 20 slots on 20 queues 18.8 M e-mails/s, on 24 queues 23.1 M; more queues than streams
