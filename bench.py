@@ -259,8 +259,9 @@ def main():
     gc.disable()
     for _ in range(args.warmup):
         step()
+    cur_stream = torch.cuda.current_stream(dev).cuda_stream
     if use_dist:
-        torch.cuda.synchronize()                      # device-wide: the slots' streams too
+        eng.join(cur_stream)
         exchange()                                    # untimed: first use of the copy kernels and of the communicator's all-gather
     fence()
     t0 = time.perf_counter()
@@ -269,9 +270,10 @@ def main():
     t_submitted = time.perf_counter() - t0            # the host side of the timed region: K submissions
     tail = [] if os.environ.get("ZKE_BENCH_TAIL_TIMES") == "1" else None      # diagnosis: where the end of the region goes
     if use_dist:
-        torch.cuda.synchronize()                      # every batch of this rank is done (device-wide wait)
-        if tail is not None:
-            tail.append(("drained", time.perf_counter() - t0))
+        # The exchange is enqueued while the batches still run: zke_engine_join orders torch's stream behind every batch in
+        # flight on the device, the host does not wait — its ~0.09 ms for the two copies and the all-gather call hide behind
+        # the drain instead of following it.  The closing fence waits for everything.
+        eng.join(cur_stream)
         exchange()
         if tail is not None:
             tail.append(("exchange enqueued", time.perf_counter() - t0))

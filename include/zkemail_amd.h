@@ -247,6 +247,10 @@ int zke_verify_batch_device(zke_engine* e, const zke_batch* in, uint64_t raw_tot
                             uint64_t domain_total, uint64_t key_total,
                             zke_result* out_dev, void* stream);
 int zke_engine_sync(zke_engine* e);
+/* Device-side join, no host wait: whatever is enqueued on `stream` (a hipStream_t; here NULL is the device's null stream)
+ * after this call runs behind every batch submitted so far, on whichever slot or stream it went.  For a consumer of the
+ * result records that lives on a stream of its own (a copy, a collective): it can be enqueued while the batches still run. */
+int zke_engine_join(zke_engine* e, void* stream);
 int zke_get_timings(zke_engine* e, zke_timings* t);                          /* the slot of the most recent batch */
 int zke_get_slot_timings(zke_engine* e, uint32_t slot, zke_timings* t);     /* the last batch that ran in `slot` */
 /* Enable per-kernel HIP-event timing (adds event records between kernels). */

@@ -83,6 +83,7 @@ def test_null_arguments_are_refused_not_dereferenced():
     assert lib.zke_verify_email_with_regex(None, None, 0, None, 0, None, 0, 0, 0, None, 0, None, 0, out.ctypes.data) == E_ARG
     assert lib.zke_engine_reserve(None, 1, 1, 1, 0) == E_ARG
     assert lib.zke_engine_sync(None) == E_ARG
+    assert lib.zke_engine_join(None, None) == E_ARG
     assert lib.zke_set_timing(None, 1) == E_ARG
     t = A.zke_timings()
     assert lib.zke_get_timings(None, C.byref(t)) == E_ARG and lib.zke_get_slot_timings(None, 0, C.byref(t)) == E_ARG

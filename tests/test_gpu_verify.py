@@ -443,6 +443,22 @@ def test_device_resident_entry_matches_host_entry():
             engine.sync()
             for k, o in enumerate(outs[:9]):
                 assert_records_equal(o.cpu().numpy().view(A.RESULT_DTYPE), host, None, f"caller-stream batch {{k}} regex={{with_regex}}")
+            # zke_engine_join: a consumer stream ordered behind every batch in flight without a host wait — 8 batches on the
+            # slots' own streams + 3 on a caller's stream, then copies of all the records enqueued on a third stream at once;
+            # only that stream is waited for
+            for o in outs:
+                o.zero_()
+            torch.cuda.synchronize()
+            for k, o in enumerate(outs[:11]):
+                engine.verify_batch_device(cb, totals[0], totals[1], totals[2], o.data_ptr(), 0 if k < 8 else sts[0].cuda_stream)
+            consumer = torch.cuda.Stream()
+            engine.join(consumer.cuda_stream)
+            with torch.cuda.stream(consumer):
+                copies = [o.clone() for o in outs[:11]]
+            consumer.synchronize()
+            for k, c in enumerate(copies):
+                assert_records_equal(c.cpu().numpy().view(A.RESULT_DTYPE), host, None, f"joined batch {{k}} regex={{with_regex}}")
+            engine.sync()
         print("device entry ok")
     """)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)

@@ -412,6 +412,24 @@ void zke_engine_destroy(zke_engine* e) {
 
 const char* zke_last_error(const zke_engine* e) { return e ? e->err.c_str() : "null engine"; }
 
+int zke_engine_join(zke_engine* e, void* stream) {
+  if (!e) return ZKE_E_ARG;
+  HIPCHK(e, hipSetDevice(e->device));
+  hipStream_t s = (hipStream_t)stream;
+  for (Slot* w : e->slots) {
+    if (!w->last_stream) continue;                       // never used
+    if (w->last_stream == w->stream) {
+      if (s == w->stream) continue;                      // stream order
+      // batches on a slot's own stream leave no event behind (release_slot): record it now, behind the last one
+      HIPCHK(e, hipEventRecord(w->done, w->stream));
+    } else if (w->last_stream == s) {
+      continue;                                          // stream order
+    }
+    HIPCHK(e, hipStreamWaitEvent(s, w->done, 0));
+  }
+  return 0;
+}
+
 int zke_engine_sync(zke_engine* e) {
   if (!e) return ZKE_E_ARG;
   HIPCHK(e, hipSetDevice(e->device));

@@ -221,7 +221,12 @@ __global__ void slot_warm_kernel(uint32_t* sink) {
 // The slot's workspace is about to be overwritten by a batch on stream s: whatever ran in it before must be over.
 // Same stream: stream order is enough.  Another stream: wait for the event recorded behind the previous batch.
 int acquire_slot(zke_engine* e, Slot& w, hipStream_t s) {
-  if (w.last_stream && w.last_stream != s) HIPCHK(e, hipStreamWaitEvent(s, w.done, 0));
+  if (w.last_stream && w.last_stream != s) {
+    // a batch on the slot's own stream leaves no event behind (release_slot): record it now, behind that batch —
+    // waiting for `done` as it stood would order this batch behind nothing
+    if (w.last_stream == w.stream) HIPCHK(e, hipEventRecord(w.done, w.stream));
+    HIPCHK(e, hipStreamWaitEvent(s, w.done, 0));
+  }
   return 0;
 }
 int release_slot(zke_engine* e, Slot& w, hipStream_t s) {

@@ -60,6 +60,8 @@ def load_library(path: Optional[str] = None):
     lib.zke_verify_batch_device.restype = C.c_int
     lib.zke_engine_sync.argtypes = [vp]
     lib.zke_engine_sync.restype = C.c_int
+    lib.zke_engine_join.argtypes = [vp, vp]
+    lib.zke_engine_join.restype = C.c_int
     lib.zke_get_timings.argtypes = [vp, C.POINTER(A.zke_timings)]
     lib.zke_get_timings.restype = C.c_int
     lib.zke_set_timing.argtypes = [vp, C.c_int]
@@ -98,7 +100,7 @@ EXPORTED_SYMBOLS = [
     "zke_verify_batch_device", "zke_engine_sync", "zke_get_timings", "zke_set_timing", "zke_verify_email",
     "zke_sha256_batch", "zke_sha256_batch_device", "zke_rsa_modexp_batch", "zke_version", "zke_device_available",
     "zke_ed25519_verify_batch", "zke_engine_reserve", "zke_get_slot_timings", "zke_verify_email_with_regex",
-    "zke_abi_encode",
+    "zke_abi_encode", "zke_engine_join",
 ]
 
 
@@ -168,6 +170,11 @@ class Engine:
 
     def sync(self):
         self._check(self.lib.zke_engine_sync(self.h), "zke_engine_sync")
+
+    def join(self, stream: int = 0):
+        """Work enqueued on `stream` (a hipStream_t handle; 0 = the null stream) from now on runs behind every batch
+        submitted so far; the host does not wait (zke_engine_join)."""
+        self._check(self.lib.zke_engine_join(self.h, stream), "zke_engine_join")
 
     def slot_timings(self, slot: int) -> dict:
         t = A.zke_timings()
