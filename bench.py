@@ -52,7 +52,7 @@ def parse_args():
                     help="skip the chip-filling SHA-256 micro-benchmark (profile runs: keeps the kernel stats to the workload's launches)")
     ap.add_argument("--streams", type=int, default=0,
                     help="submission slots of the engine = batches in flight per GPU: step i runs in slot i %% S (a stream and a "
-                         "workspace each; one engine, one key cache); 1 = strictly serial steps.  Default: 22 on one GPU, 16 when "
+                         "workspace each; one engine, one key cache); 1 = strictly serial steps.  Default: 22 on one GPU, 18 when "
                          "the rank holds an RCCL communicator (N > 1)")
     ap.add_argument("--alone-steps", type=int, default=8,
                     help="steps of the extra pass that runs one batch at a time (per-kernel times of a batch alone); 0 = skip "
@@ -61,8 +61,18 @@ def parse_args():
 
 
 def default_slots(with_communicator: bool) -> int:
-    """Submission slots per GPU when --streams is not given: 22 alone, 16 beside an RCCL communicator (main() says why)."""
-    return 16 if with_communicator else 22
+    """Submission slots per GPU when --streams is not given: 22 alone, 18 beside an RCCL communicator (main() says why)."""
+    return 18 if with_communicator else 22
+
+
+def queue_cap(slots: int, with_communicator: bool) -> int:
+    """GPU_MAX_HW_QUEUES for a rank: the size of HIP's pool of hardware queues (streams beyond it share queues).  The chip runs 24
+    queues of a process without time-slicing them; the 25th costs a factor of ten (main()).  Alone, only the slots and the null stream
+    exist: S + 4, but never more than 23 — a stream created on top then shares a queue instead of becoming the 25th (22 slots
+    under a cap of 23 run as under 26: 30.4 M e-mails/s).  Beside a communicator the pool is what keeps the count down: S + 2, at
+    most 22 — the slots and the null stream get a queue each, RCCL's own streams (idle while batches run) share, and torch's
+    high-priority collective stream, which has a pool of its own, still fits under the limit."""
+    return max(4, min(slots + 2, 22)) if with_communicator else max(4, min(slots + 4, 23))
 
 
 def spawn_ranks(args):
@@ -128,11 +138,14 @@ def main():
     if world != args.gpus and world > 1:
         args.gpus = world
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    # Slots: a stream each, and every stream wants a hardware queue of its own.  The chip schedules a limited number of queues
-    # per process without time-slicing them; past it (48 streams: 0.7 M e-mails/s in the burst) batches wait milliseconds for
-    # their queue's turn.  22 slots + the null stream sit just under the limit on one GPU.  A communicator brings a handful of
-    # streams of its own (RCCL's internal ones, torch's collective stream): with it 20 slots are already over — the 20-step burst
-    # takes 7-50 ms instead of 1.3, the steady state halves — 18 are fine, 16 leave a margin (profiles/r02_dist_queues.txt).
+    # Slots: a stream each, and every stream wants a hardware queue of its own.  The chip runs 24 queues of a process without
+    # time-slicing them; with a 25th, batches wait milliseconds for their queue's turn (24 slots + the null stream: 21.7 M e-mails/s
+    # instead of 27.4 M; 48 streams: 0.7 M in the burst).  22 slots + the null stream sit under the limit on one GPU.  A communicator
+    # brings streams of its own (RCCL's internal ones, torch's collective stream): with a roomy queue pool 20 slots are then already
+    # over — the 20-step burst 7-50 ms instead of 1.3, the steady state halved.  What keeps a rank under the limit is the CAP on
+    # HIP's queue pool, not the stream count: 22 slots beside a communicator run at 29.8 M with GPU_MAX_HW_QUEUES = 23 and at 2.5 M /
+    # 21.7 M (burst / steady) with 24.  A rank with a communicator runs 18 slots under a cap of 20: three queues of margin
+    # (profiles/r02_dist_queues.txt).
     will_dist = int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("ZKE_BENCH_FORCE_DIST") == "1"
     if args.streams <= 0:
         args.streams = default_slots(will_dist)
@@ -141,7 +154,7 @@ def main():
     # sharing one (measured: 20 slots on 20 queues 18.8 M e-mails/s, on 24 queues 23.1 M; more queues than streams
     # change nothing, but idle queues beyond ~32 cost: 40 mapped queues 11.9 M).  22 slots on 26 queues is the measured
     # optimum (20 / 21 / 22 / 24 slots: 26.1 / 26.8 / 27.4 / 21.7 M).  profiles/r02_hw_queues.txt
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, min(args.streams, 28) + 4)))
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(queue_cap(args.streams, will_dist)))
 
     import torch
     import torch.distributed as dist

@@ -12,9 +12,15 @@ sys.path.insert(0, ROOT)
 def test_slot_default_leaves_room_for_the_communicators_streams():
     import bench
     assert bench.default_slots(False) == 22
-    assert bench.default_slots(True) == 16
-    # 18 is the last count measured good beside a communicator, 20 the first bad one
-    assert bench.default_slots(True) <= 18 < 20 <= bench.default_slots(False)
+    assert bench.default_slots(True) == 18
+    # the chip runs 24 queues of a process without time-slicing: alone the slots + the null stream stay under it by count,
+    # beside a communicator the pool's cap does (torch's collective stream has a pool of its own: + 1)
+    assert bench.default_slots(False) + 1 <= 24 and bench.queue_cap(22, False) == 23
+    assert bench.queue_cap(bench.default_slots(True), True) == 20
+    for s in range(1, 65):
+        assert bench.queue_cap(s, True) + 1 <= 23          # at least one queue of margin whatever --streams says
+        assert bench.queue_cap(s, False) <= 23
+        assert bench.queue_cap(s, False) >= min(s + 1, 23)  # room for the slots + the null stream up to the limit
 
 
 def test_bench_without_gpu_fails_loudly_and_prints_nothing_on_stdout():

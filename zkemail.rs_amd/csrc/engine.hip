@@ -295,8 +295,10 @@ int set_stage_attr_any(zke_engine* e) {
 
 // HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and reads the variable when the runtime
 // initialises.  A process that loads this library before it first touches HIP (every C / C++ / Rust host that links it)
-// gets room for 22 submission slots unless it has set the variable itself; DESIGN.md §5, INTEGRATION.md §5.
-__attribute__((constructor)) static void zke_default_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "26", 0); }
+// gets room for 22 submission slots + the null stream unless it has set the variable itself — and no more: the chip runs 24
+// queues of a process without time-slicing them, the 25th costs a factor of ten, and with the pool capped at 23 a stream the
+// process creates on top (a communicator's, a framework's) shares a queue instead of adding one; DESIGN.md §5, INTEGRATION.md §5.
+__attribute__((constructor)) static void zke_default_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "23", 0); }
 
 extern "C" {
 
