@@ -270,6 +270,15 @@ def main():
     import gc
     gc.collect()
     gc.disable()
+    # One real batch through every slot before the W warm-up steps (the advisor's reading of "warm": W = 5 touches five of the
+    # 22 slots; zke_engine_reserve has run an EMPTY batch through each, which sizes and touches the workspaces but is not the
+    # submit path at size).  Reported as warmup_effective.  On a box's very first run the driver's burst has come out at 10 M
+    # e-mails/s with the host needing 0.83 ms instead of 0.2 for the 20 submissions: whatever the runtime sets up lazily per
+    # queue is paid here, not there.
+    priming = S if S > 1 else 0
+    for _ in range(priming):
+        step()
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     cur_stream = torch.cuda.current_stream(dev).cuda_stream
@@ -305,7 +314,7 @@ def main():
 
     # ---- correctness of what was timed (outside the timed region)
     nocheck = os.environ.get("ZKE_BENCH_NOCHECK") == "1"       # kernel-ablation experiments only: results are not valid
-    first_timed = args.warmup
+    first_timed = priming + args.warmup
     written = sorted({i % n_slices for i in range(first_timed, counter[0])})
     for sl in ([] if nocheck else sorted(set(written[:S]) | set(written[-2:]))):
         rec = results_all[sl * rec_bytes:(sl + 1) * rec_bytes].cpu().numpy().view(A.RESULT_DTYPE)
@@ -423,7 +432,7 @@ def main():
 
     out = {
         "metric": "emails verified/sec (witness gen)", "value": round(emails_per_s, 1), "unit": "emails/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_effective": priming + args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[1]: batch {n} e-mails, 4 KB body, RSA-2048, DKIM-only verify_email"
                    if args.workload == "c2" else f"{args.workload}: {cfg}",
