@@ -149,11 +149,9 @@ def main():
     will_dist = int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("ZKE_BENCH_FORCE_DIST") == "1"
     if args.streams <= 0:
         args.streams = default_slots(will_dist)
-    # HIP multiplexes streams onto 4 hardware queues by default.  Every slot stream needs a queue of its own, and the
-    # null stream and the runtime's own queues come out of the same pool: with exactly S queues two slots end up
-    # sharing one (measured: 20 slots on 20 queues 18.8 M e-mails/s, on 24 queues 23.1 M; more queues than streams
-    # change nothing, but idle queues beyond ~32 cost: 40 mapped queues 11.9 M).  22 slots on 26 queues is the measured
-    # optimum (20 / 21 / 22 / 24 slots: 26.1 / 26.8 / 27.4 / 21.7 M).  profiles/r02_hw_queues.txt
+    # HIP multiplexes streams onto 4 hardware queues by default; the pool is sized here, before HIP initialises (queue_cap).
+    # With fewer queues than slots + 1 two slots share one (20 slots on 20 queues 18.8 M e-mails/s, on 24 queues 23.1 M);
+    # 20 / 21 / 22 / 24 slots: 26.1 / 26.8 / 27.4 / 21.7 M.  profiles/r02_hw_queues.txt
     os.environ.setdefault("GPU_MAX_HW_QUEUES", str(queue_cap(args.streams, will_dist)))
 
     import torch
