@@ -14,9 +14,13 @@ timed region when N > 1.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` (the hash / modexp launch —
 SHA-256 groups beside the RSA roles — HIP-event timed on its slot's stream, with S batches in flight as in the timed
-region; the figures of a batch alone and of the timed region as a whole beside it) and `cpu_baseline` (the CPU oracle —
-a port, not the Rust reference — on this box's host cores).  `python bench.py --gpus N` without a launcher starts its
-N ranks itself (torch.distributed.run, one process per GPU).
+region; the figures of a batch alone and of the timed region as a whole beside it; the instruction-issue bound that
+actually binds the step beside the HBM fraction the metric asks for), `end_to_end` (the same workload from pageable host
+memory through zke_verify_batch_async: H2D and D2H inside the clock), `single_email_latency_us` (zke_verify_email, p50,
+beside the oracle's) and `cpu_baseline` (the CPU oracle — a port, not the Rust reference — on this box's host cores).
+`python bench.py --gpus N` without a launcher starts its N ranks itself (torch.distributed.run, one process per GPU).
+`--scaling strong --workload c4` runs BASELINE configs[3] as worded: ONE batch of 65 536 e-mails sharded by bytes over
+the N ranks (zkemail.rs_amd/distributed.py ShardedVerifier), witnesses all-gathered.
 """
 from __future__ import annotations
 
@@ -40,11 +44,19 @@ def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c4shard", "c5", "c2ed", "c3", "c5re"],
+    ap.add_argument("--warmup", type=int, default=100,
+                    help="untimed steps in front of the timed ones.  On top of them every submission slot is primed with ONE real "
+                         "batch first (S = --streams of them; `warmup_effective` in the JSON line = S + W): W = 5 would touch 5 of 22 slots")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c4shard", "c5", "c2ed", "c3", "c5re", "c2ragged", "c2inv", "c4"],
                     help="c2 = BASELINE configs[1] (default); c4shard = one GPU's shard of configs[3]; c5 = configs[4] shape; "
                          "c2ed = the c2 shape signed a=ed25519-sha256 (SURVEY §8(f) row f4); c3 = configs[2] (verify_email_with_regex, "
-                         "2 header parts); c5re = configs[4] shape (RSA-4096, QP soft breaks, 2 header + 2 body parts)")
+                         "2 header parts); c5re = configs[4] shape (RSA-4096, QP soft breaks, 2 header + 2 body parts); "
+                         "c2ragged = configs[1] with body lengths log-uniform in 3 B .. 64 KB (SURVEY §8(d)); c2inv = configs[1] with 1 %% "
+                         "invalid e-mails (flipped body / header byte); c4 = configs[3] as worded, with --scaling strong")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): every rank verifies its own batch of the configured size.  strong: ONE batch of the "
+                         "configured size, sharded by cumulative bytes over the ranks (ShardedVerifier)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (host-memory entry) and single-e-mail latency legs")
     ap.add_argument("--batch", type=int, default=0, help="override e-mails per step (default: the config's batch)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU baseline sample budget per leg")
     ap.add_argument("--no-cpu", action="store_true")
@@ -185,7 +197,12 @@ def main():
         "c2ed": dict(n=1024, body_len=4096, n_keys=16, algo="ed25519-sha256"),
         "c3": dict(n=4096, body_len=4096, rsa_bits=2048, n_keys=16, n_header_parts=2, n_body_parts=0),
         "c5re": dict(n=2048, body_len=4096, rsa_bits=4096, n_keys=16, n_header_parts=2, n_body_parts=2, qp_frac=0.05),
+        "c2ragged": dict(n=1024, body_len=65536, rsa_bits=2048, n_keys=16, ragged=True),     # log-uniform 3 B .. 64 KB (mean ~6.5 KB)
+        "c2inv": dict(n=1024, body_len=4096, rsa_bits=2048, n_keys=16, invalid_frac=0.01),
+        "c4": dict(n=65536, body_len=65536, rsa_bits=2048, n_keys=16),
     }
+    if args.scaling == "strong":
+        return strong_scaling_main(args, cfgs, rank, local_rank, world, json_fd)
     cfg = dict(cfgs[args.workload])
     if args.batch:
         cfg["n"] = args.batch
@@ -201,7 +218,8 @@ def main():
     # kernel attributes exist once).  S batches are in flight: a step is still one batch of n e-mails, consecutive steps
     # simply do not wait for each other, as a service with a queue of batches would run them.  The inputs are read-only
     # and shared.  zke_engine_reserve sizes every slot now: nothing is allocated once the steps start.
-    eng = z.Engine(device=local_rank)
+    host_cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    eng = z.Engine(device=local_rank, host_threads=max(1, min(8, host_cores // 2)))
     if regex_inputs is not None:
         packed = eng.pack_with_regex(regex_inputs)           # registers the DFAs of the part list
     else:
@@ -316,15 +334,18 @@ def main():
     written = sorted({i % n_slices for i in range(first_timed, counter[0])})
     for sl in ([] if nocheck else sorted(set(written[:S]) | set(written[-2:]))):
         rec = results_all[sl * rec_bytes:(sl + 1) * rec_bytes].cpu().numpy().view(A.RESULT_DTYPE)
-        n_ok = int((rec["status"] == 0).sum())
-        if n_ok != n:
-            raise SystemExit(f"rank {rank}: {n - n_ok} of {n} synthetic e-mails did not verify — benchmark invalid")
+        expect_ok = np.array([it.get("corrupt") is None for it in wl.inter])
+        if not ((rec["status"] == 0) == expect_ok).all():
+            bad = int(((rec["status"] == 0) != expect_ok).sum())
+            raise SystemExit(f"rank {rank}: {bad} of {n} synthetic e-mails came out other than the signer expects — benchmark invalid")
         for j in range(0, n, max(1, n // 16)):
             it = wl.inter[j]
-            assert bytes(rec[j]["body_hash"]) == it["body_hash"] and bytes(rec[j]["header_hash"]) == it["header_hash"]
+            if it.get("corrupt") is None:
+                assert bytes(rec[j]["body_hash"]) == it["body_hash"] and bytes(rec[j]["header_hash"]) == it["header_hash"]
     if use_dist and not nocheck:
         ok_all = int((gathered_all.view(torch.int32).view(-1, 18)[:, 0] == 0).sum().item())      # status word of every witness
-        assert ok_all == world * g_steps * n, (ok_all, world * g_steps * n)
+        if not cfg.get("invalid_frac"):
+            assert ok_all == world * g_steps * n, (ok_all, world * g_steps * n)
         mine = gathered_all[rank * g_steps * wit_bytes:(rank + 1) * g_steps * wit_bytes]
         assert bool((mine == D.witness_tensor(results_all[:g_steps * rec_bytes])).all().item())
 
@@ -353,80 +374,104 @@ def main():
     eng.set_timing(False)
 
     emails_per_s = world * n * args.steps / dt
-    # the hash / modexp launch: algorithmic bytes = every byte hashed once + 32 B per digest ...
-    hashed = wl.body_bytes + sum(len(it["canon_header"]) for it in wl.inter) + \
-        sum(len(e.from_domain.encode()) + len(e.public_key.key) for e in wl.emails)
-    # ... and the launch's RSA roles read the signature and the modulus (k bytes each), the key's cached R^2 (k bytes) and
-    # leave 36 bytes (EM's shape verdict + digest) per e-mail: 3 k + 36 = 804 B at RSA-2048
+    # The SHA-256 body kernel's algorithmic bytes, SURVEY §8(d): every canonical body byte read once + 32 B written per e-mail ...
+    body_bytes = wl.body_bytes + 32 * n
+    # ... and everything else the hash / modexp launch moves: the header preimages, domains and keys it also hashes (+ 32 B per
+    # digest), and the RSA roles' operands — signature and modulus (k bytes each), the key's cached R^2 (k bytes), 36 bytes out
+    # (EM's shape verdict + digest) per e-mail: 3 k + 36 = 804 B at RSA-2048
+    other_hashed = sum(len(it["canon_header"]) for it in wl.inter) + \
+        sum(len(e.from_domain.encode()) + len(e.public_key.key) for e in wl.emails) + 32 * 3 * n
     k_rsa = cfg.get("rsa_bits", 0) // 8
     rsa_bytes = n * (3 * k_rsa + 36) if k_rsa else 0
-    sha_bytes = hashed + 32 * 4 * n + rsa_bytes
-    sha_s = kern_flight["sha_us"] * 1e-6
-    # HBM traffic of that launch from the PMC counters (rocprofv3 --pmc passes, committed under profiles/)
-    traffic, traffic_src = None, None
-    for pmc_name in ("r02_c2_sha_pmc.json", "r01_c2_sha_pmc.json"):
-        pmc_file = os.path.join(ROOT, "profiles", pmc_name)
-        if args.workload == "c2" and not args.batch and os.path.exists(pmc_file):
-            traffic, traffic_src = int(json.load(open(pmc_file))["hbm_bytes_per_launch"]), "profiles/" + pmc_name
-            break
-    gbps_of = (lambda us: round(sha_bytes / (us * 1e-6) / 1e9, 3) if us and us > 0 else None)
+    launch_bytes = body_bytes + other_hashed + rsa_bytes
+    # PMC figures of that launch come from separate rocprofv3 --pmc passes over this bench (they cannot run inside the timed
+    # run); the committed summaries of the tree's last profiling session are quoted, with their file names
+    prof = load_profile_figures(args, n)
+    gbps_of = (lambda nbytes, us: round(nbytes / (us * 1e-6) / 1e9, 3) if us and us > 0 else None)
+    frac_of = (lambda g: round(g / HBM_PEAK_GBS, 5) if g is not None else None)
     step_s = dt / args.steps
-    agg_gbs = round(sha_bytes / step_s / 1e9, 3)
+    agg_gbs = round(body_bytes / step_s / 1e9, 3)
+    fused = (4 * ((n + 63) // 64)) <= 512
+    # The bound that binds: instruction issue.  The step's VALU wave-instructions (PMC: SQ_INSTS_VALU summed over the three
+    # launches of a batch) x 3.9 cycles per instruction and SIMD (measured: profiles/r01_ubench_valu_rate.txt) on 1 024 SIMDs
+    # at 2.4 GHz is the time the chip needs to ISSUE one batch, whatever overlaps with whatever.
+    issue = None
+    if prof.get("valu_per_batch"):
+        issue_us = prof["valu_per_batch"] * 3.9 / (1024 * 2400.0)
+        issue = {"issue_bound_us_per_step": round(issue_us, 2), "frac_of_issue_bound": round(issue_us / (step_s * 1e6), 4),
+                 "valu_wave_instr_per_batch": prof["valu_per_batch"], "salu_wave_instr_per_batch": prof.get("salu_per_batch"),
+                 "source": prof["instr_source"],
+                 "how": "VALU wave-instructions per batch (PMC) x 3.9 cycles / (1024 SIMDs x 2.4 GHz); frac = that / measured us per step"}
+    def per_launch(t, how):
+        if not t:
+            return None
+        us = t["hash_modexp_us"]
+        g = gbps_of(body_bytes, us)
+        return {"launch_us": round(us, 2), "achieved": g, "frac": frac_of(g), "achieved_all_bytes": gbps_of(launch_bytes, us), "how": how}
     roof = {
-        "bound": "hbm", "kernel": "hash_modexp_kernel<128> (SHA-256 groups + RSA roles, one launch)" if (4 * ((n + 63) // 64)) <= 512 else "sha256_batch_kernel<128>",
+        "bound": "hbm", "kernel": "hash_modexp_kernel<128> (SHA-256 groups + RSA roles, one launch)" if fused else "sha256_batch_kernel<128>",
         # The timed region keeps S launches of this kernel in flight: the chip-level rate is one launch's bytes per
         # ms_per_step (the wall time the timed region spends per launch).  The latency of a single launch, under that load
         # and alone, is given beside it — bytes / launch_us of those is what ONE launch achieves, not the chip.
         "mode": f"timed region: {S} batches in flight; achieved = bytes_per_launch / ms_per_step (one launch of this kernel per step, "
                 f"{S} of them overlapping)",
         "achieved": agg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(agg_gbs / HBM_PEAK_GBS, 5),
-        "traffic": traffic, "traffic_source": traffic_src, "bytes_per_launch": sha_bytes, "hashed_bytes": hashed + 32 * 4 * n,
-        "rsa_operand_bytes": rsa_bytes, "ms_per_step": round(step_s * 1e3, 4),
+        "bytes_per_launch": body_bytes,
+        "bytes_definition": "SURVEY §8(d): sum of canonical body lengths + 32 B per e-mail (the SHA-256 body kernel)",
+        "bytes_per_launch_all": launch_bytes,
+        "achieved_all_bytes": round(launch_bytes / step_s / 1e9, 3),
+        "all_bytes_definition": "+ header preimages, domains and keys hashed in the same launch (+ 32 B per digest) + RSA operands (3k + 36 B per e-mail)",
+        "traffic": prof.get("hbm_bytes_per_launch"), "traffic_source": prof.get("traffic_source"),
+        "ms_per_step": round(step_s * 1e3, 4),
+        "issue_bound": issue,
         "per_launch": {
-            "in_flight": {"launch_us": round(kern_flight["sha_us"], 2), "achieved": gbps_of(kern_flight["sha_us"]),
-                          "frac": round(gbps_of(kern_flight["sha_us"]) / HBM_PEAK_GBS, 5),
-                          "how": f"HIP events around the launch on its slot's stream with {S} batches in flight (includes the wait for "
-                                 "the chip behind the previous launch of the batch; rocprofv3's kernel-only average is in "
-                                 "profiles/r02_bench_c2_inflight_kernel_stats.csv)"},
-            "alone": {"launch_us": round(kern_alone["sha_us"], 2), "achieved": gbps_of(kern_alone["sha_us"]),
-                      "frac": round(gbps_of(kern_alone["sha_us"]) / HBM_PEAK_GBS, 5),
-                      "how": "one batch at a time (--alone-steps); rocprofv3: profiles/r02_bench_c2_streams1_kernel_stats.csv"} if kern_alone else None,
+            "in_flight": per_launch(kern_flight, f"HIP events around the launch on its slot's stream with {S} batches in flight (includes the wait "
+                                    "for the chip behind the previous launch of the batch); rocprofv3's kernel-only average: "
+                                    "profiles/r03_bench_c2_inflight_kernel_stats.csv"),
+            "alone": per_launch(kern_alone, "one batch at a time (--alone-steps); rocprofv3: profiles/r03_bench_c2_streams1_kernel_stats.csv"),
         },
         "note": "SHA-256 on CDNA4 is integer-VALU bound: the compression alone sustains 1.82 TB/s on this chip "
                 "(profiles/r01_ubench_sha_alu.txt: ~1400 VALU per 64-byte block at ~3.9 cycles each), and a 1024-message launch is "
                 "bounded by the dependency chain of one message (65 blocks) and of one RSA wave beside it; see DESIGN.md §3",
     }
 
-    # ---- the same SHA-256 kernel with enough independent messages to fill the chip (kernel capability, not the
-    # workload's roofline): 2^18 messages x 4 KiB resident in HBM, HIP-event timed on the launch stream
+    # ---- the SHA-256 kernels with enough independent messages to fill the chip (kernel capability, not the workload's
+    # roofline), messages resident in HBM, HIP-event timed on the launch stream:
+    #   (a) sha256_batch_kernel<128>, one wave per 64 messages — what launches of more than 512 groups use: 2^18 x 4 KiB;
+    #   (b) sha256_pair_kernel<128> = sha256_pair_group, the routine the timed hash / modexp launch runs, at its largest
+    #       launch (512 groups = 32 768 messages): two waves per 64 messages, one group per two SIMDs
     sha_sat = None
     if rank == 0 and world == 1 and not args.no_saturated:
-        nm, ml = 1 << 18, 4096
-        blob = torch.randint(0, 256, (nm * ml + 64,), dtype=torch.uint8, device=dev)
-        off = (torch.arange(nm + 1, dtype=torch.int64, device=dev) * ml)
-        dig = torch.zeros(nm * 32, dtype=torch.uint8, device=dev)
-        cur = torch.cuda.Stream(device=dev)          # a real (non-null) HIP stream: the engine launches on the handle it is given
-        torch.cuda.synchronize()
-        lib = eng.lib
-        for _ in range(2):
-            lib.zke_sha256_batch_device(eng.h, blob.data_ptr(), off.data_ptr(), nm, dig.data_ptr(), cur.cuda_stream)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 5
-        e0.record(cur)
-        for _ in range(reps):
-            lib.zke_sha256_batch_device(eng.h, blob.data_ptr(), off.data_ptr(), nm, dig.data_ptr(), cur.cuda_stream)
-        e1.record(cur)
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / reps
         import hashlib
-        for i in (0, nm // 2, nm - 1):
-            assert bytes(dig[32 * i:32 * i + 32].cpu().numpy()) == hashlib.sha256(bytes(blob[i * ml:(i + 1) * ml].cpu().numpy())).digest()
-        gbs = (nm * (ml + 32)) / (ms * 1e-3) / 1e9
-        sha_sat = {"messages": nm, "message_bytes": ml, "ms_per_launch": round(ms, 3), "achieved_GBps": round(gbs, 1),
-                   "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4), "valu_ceiling_GBps": 1820,
-                   "note": "includes the small job-list kernel; ceiling = register-only compression rate measured on this chip "
-                           "(tools/ubench/sha_alu.hip)"}
-        del blob, off, dig
+        lib = eng.lib
+
+        def saturate(nm, ml, kernel, reps=5):
+            blob = torch.randint(0, 256, (nm * ml + 64,), dtype=torch.uint8, device=dev)
+            off = (torch.arange(nm + 1, dtype=torch.int64, device=dev) * ml)
+            dig = torch.zeros(nm * 32, dtype=torch.uint8, device=dev)
+            cur = torch.cuda.Stream(device=dev)          # a real (non-null) HIP stream: the engine launches on the handle it is given
+            torch.cuda.synchronize()
+            for _ in range(2):
+                lib.zke_sha256_batch_device(eng.h, blob.data_ptr(), off.data_ptr(), nm, dig.data_ptr(), cur.cuda_stream)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(cur)
+            for _ in range(reps):
+                lib.zke_sha256_batch_device(eng.h, blob.data_ptr(), off.data_ptr(), nm, dig.data_ptr(), cur.cuda_stream)
+            e1.record(cur)
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            for i in (0, nm // 2, nm - 1):
+                assert bytes(dig[32 * i:32 * i + 32].cpu().numpy()) == hashlib.sha256(bytes(blob[i * ml:(i + 1) * ml].cpu().numpy())).digest()
+            gbs = (nm * (ml + 32)) / (ms * 1e-3) / 1e9
+            return {"kernel": kernel, "messages": nm, "message_bytes": ml, "ms_per_launch": round(ms, 3), "achieved_GBps": round(gbs, 1),
+                    "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4), "frac_of_valu_ceiling": round(gbs / 1820.0, 4)}
+
+        sha_sat = saturate(1 << 18, 4096, "sha256_batch_kernel<128> (one wave per 64 messages)")
+        sha_sat["valu_ceiling_GBps"] = 1820
+        sha_sat["note"] = ("includes the small job-list kernel; ceiling = register-only compression rate measured on this chip "
+                           "(tools/ubench/sha_alu.hip); rocprofv3 + PMC of this launch: profiles/r03_sha_saturated_*")
+        sha_sat["pair_kernel"] = saturate(1 << 15, 4096, "sha256_pair_kernel<128> = sha256_pair_group, the timed launch's SHA-256 routine "
+                                          "(two waves per 64 messages), at its largest launch: 512 groups")
 
     out = {
         "metric": "emails verified/sec (witness gen)", "value": round(emails_per_s, 1), "unit": "emails/s",
@@ -434,9 +479,11 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[1]: batch {n} e-mails, 4 KB body, RSA-2048, DKIM-only verify_email"
                    if args.workload == "c2" else f"{args.workload}: {cfg}",
-                   "emails_per_step_per_gpu": n, "body_bytes": cfg["body_len"], "rsa_bits": cfg.get("rsa_bits", 0), "algo": cfg.get("algo", "rsa-sha256"),
+                   "emails_per_step_per_gpu": n, "body_bytes": cfg["body_len"], "mean_hashed_body_bytes": round(wl.body_bytes / n, 1),
+                   "rsa_bits": cfg.get("rsa_bits", 0), "algo": cfg.get("algo", "rsa-sha256"),
                    "inputs": "HBM-resident raw e-mails", "batches_in_flight": S, "collective": "one RCCL all_gather of every step's 72-B witnesses (status + output hashes of each e-mail) at the end of the timed region" if use_dist else "none"},
         "roofline": roof,
+        "hashed_body_GBps": round(wl.body_bytes / step_s / 1e9, 3),
         "kernels_us_in_flight": {k: round(v, 2) for k, v in kern_flight.items()},
         "kernels_us_alone": {k: round(v, 2) for k, v in kern_alone.items()} if kern_alone else None,
         "host_submit_ms": round(t_submitted * 1e3, 3),
@@ -444,12 +491,29 @@ def main():
         "workload_gen_s": round(gen_s, 2),
     }
 
-    # ---- CPU baseline: the oracle (port) on this box's host cores, rank 0, N = 1 only
+    # ---- end to end: the same workload from pageable host memory (what a drop-in caller holds: core/src/circuits.rs:9 takes a
+    # RAM-resident &Email), zke_verify_batch_async through every slot, H2D and D2H inside the clock; and the latency of ONE call
+    orc = None
     if rank == 0 and world == 1 and not args.no_cpu:
         import oracle_lib
         orc = oracle_lib.load()
+    if rank == 0 and world == 1 and not args.no_e2e:
+        # pinned staging is S slots x one batch's inputs: beyond 4 GiB (configs[3]'s shard: 0.5 GiB per batch) a fresh engine with
+        # fewer slots takes the leg (the first one is closed first: two engines' streams would exceed the chip's hardware queues)
+        img = totals[0] + totals[1] + totals[2]
+        S_host = S if S * img <= (4 << 30) else max(2, (4 << 30) // img)
+        if S_host != S and regex_inputs is None:
+            eng.close()
+            eng = z.Engine(device=local_rank, slots=S_host, host_threads=int(eng.options.host_threads))
+            eng.reserve(n, totals[0], S_host, 0)
+        if S_host == S or regex_inputs is None:
+            out["end_to_end"] = end_to_end_leg(torch, dev, eng, packed, n, S_host, totals, wl)
+            out["single_email_latency_us"] = latency_leg(eng, packed, wl, regex_inputs, orc)
+
+    # ---- CPU baseline: the oracle (port) on this box's host cores, rank 0, N = 1 only
+    if orc is not None:
         cpu_packed = orc.pack_with_regex(regex_inputs) if regex_inputs is not None else packed     # the oracle has its own DFA registry
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        cores = host_cores
 
         def cpu_leg(threads):
             reps, t_used = 0, 0.0
@@ -458,13 +522,13 @@ def main():
                 r = orc.verify_batch(cpu_packed, threads=threads)
                 reps += 1
                 t_used = time.perf_counter() - t_start
-            assert (r["status"] == 0).all()
+            assert ((r["status"] == 0) == np.array([it.get("corrupt") is None for it in wl.inter])).all()
             return reps * n / t_used, reps
 
         one, reps1 = cpu_leg(1)
         allc, repsn = cpu_leg(cores)
         out["cpu_baseline"] = {
-            "value": round(allc, 1), "unit": "emails/s", "cores": cores, "kind": "port",
+            "value": round(allc, 1), "unit": "emails/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
             "sample": f"{repsn} x the same {n}-e-mail batch, one worker thread per core ({args.cpu_seconds:.0f} s budget); "
                       f"CPU restatement of the zkemail_core path (oracle/zke_oracle.c, SHA-NI {'on' if orc.lib.zko_sha256_uses_shani() else 'off'})",
             "single_thread_value": round(one, 1),
@@ -472,6 +536,207 @@ def main():
         out["gpu_over_cpu"] = round(emails_per_s / allc, 2)
     if rank == 0:
         sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if use_dist:
+        dist.destroy_process_group()
+
+
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def load_profile_figures(args, n):
+    """PMC figures of the bench workload from the committed rocprofv3 summaries (profiles/, newest round first): the VALU / SALU
+    wave-instructions of one batch (sum over its three launches) and the HBM bytes of the hash / modexp launch.  Only for the
+    workload they were taken on (c2 at its configured batch size); None otherwise."""
+    out = {}
+    if args.workload != "c2" or args.batch:
+        return out
+    for rnd in ("r03", "r02", "r01"):
+        f = os.path.join(ROOT, "profiles", f"{rnd}_c2_instr_pmc.json")
+        if os.path.exists(f):
+            j = json.load(open(f))
+            ks = [k for k in j if any(t in k for t in ("parse_kernel", "hash_modexp_kernel", "ed_verdict_kernel"))]
+            out["valu_per_batch"] = round(sum(j[k]["SQ_INSTS_VALU"] for k in ks))
+            out["salu_per_batch"] = round(sum(j[k]["SQ_INSTS_SALU"] for k in ks))
+            out["instr_source"] = f"profiles/{rnd}_c2_instr_pmc.json"
+            break
+    for rnd in ("r03", "r02", "r01"):
+        f = os.path.join(ROOT, "profiles", f"{rnd}_c2_sha_pmc.json")
+        if os.path.exists(f):
+            out["hbm_bytes_per_launch"] = int(json.load(open(f))["hbm_bytes_per_launch"])
+            out["traffic_source"] = f"profiles/{rnd}_c2_sha_pmc.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this bench, --streams 1)"
+            break
+    return out
+
+
+def end_to_end_leg(torch, dev, eng, packed, n, S, totals, wl, seconds=2.0):
+    """e-mails/s through the host-memory entry point: every step hands zke_verify_batch_async the SAME pageable numpy arrays (the
+    entry reads them completely before it returns), S batches in flight, each batch waited for when its slot comes round again.
+    The clock runs from the first submission to the last record delivered: packing into pinned memory, H2D, the launches, D2H and
+    the copy of the records to the caller's array are all inside."""
+    from zkemail_rs_amd import _abi as A
+    import ctypes as C
+    lib, h = eng.lib, eng.h
+    outs = [np.zeros(n, dtype=A.RESULT_DTYPE) for _ in range(S)]
+    tickets = [None] * S
+    eng.reserve_host(n, totals[0] + totals[1] + totals[2] + int(packed.cap_str_off[-1]) + 4 * (len(packed.cap_off) + len(packed.cap_str_off)))
+
+    def run(steps):
+        t0 = time.perf_counter()
+        for i in range(steps):
+            k = i % S
+            if tickets[k] is not None:
+                assert lib.zke_batch_wait(h, tickets[k]) == 0
+            t = C.c_uint64()
+            rc = lib.zke_verify_batch_async(h, C.byref(packed.c), outs[k].ctypes.data, C.byref(t))
+            assert rc == 0, lib.zke_last_error(h)
+            tickets[k] = t.value
+        for k in range(S):
+            if tickets[k] is not None:
+                assert lib.zke_batch_wait(h, tickets[k]) == 0
+                tickets[k] = None
+        return time.perf_counter() - t0
+
+    run(2 * S)                                            # every slot's staging has been used once
+    probe = run(2 * S) / (2 * S)
+    steps = int(max(3 * S, min(20000, seconds / max(probe, 1e-6))))
+    dt = run(steps)
+    expect_ok = np.array([it.get("corrupt") is None for it in wl.inter])
+    for o in outs:
+        assert ((o["status"] == 0) == expect_ok).all(), "end-to-end leg: records differ from what the signer expects"
+    bytes_in = totals[0] + totals[1] + totals[2] + 3 * 8 * (n + 1) + 2 * n          # what crosses PCIe per batch, host to device
+    bytes_out = 192 * n
+    # the link itself: one pinned 256 MiB buffer to HBM and back, timed with events (what a DMA engine moves, no packing)
+    pin = torch.empty(256 << 20, dtype=torch.uint8, pin_memory=True)
+    dst = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    dst.copy_(pin, non_blocking=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(4):
+        dst.copy_(pin, non_blocking=True)
+    e1.record()
+    torch.cuda.synchronize()
+    link = 4 * (256 << 20) / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    rate = steps * n / dt
+    h2d = steps * bytes_in / dt / 1e9
+    return {"value": round(rate, 1), "unit": "emails/s", "entry": "zke_verify_batch_async + zke_batch_wait, pageable host memory in, records out",
+            "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4), "batches_in_flight": S, "host_threads": int(eng.options.host_threads),
+            "bytes_per_email_h2d": round(bytes_in / n, 1), "bytes_per_email_d2h": 192,
+            "h2d_GBps": round(h2d, 2), "pcie_h2d_GBps_pinned_link": round(link, 2), "frac_of_pcie": round(h2d / link, 4),
+            "emails_per_s_pcie_allows": round(link * 1e9 / (bytes_in / n), 1)}
+
+
+def latency_leg(eng, packed, wl, regex_inputs, orc, calls=300):
+    """One call, one e-mail: what the reference's call pattern costs (core/src/circuits.rs:9 is called per e-mail).  p50 / p90 of
+    zke_verify_email over `calls` calls of one e-mail of the workload; the time of host-entry batches of 1 .. 64 e-mails; the
+    oracle's time for the same e-mail on one core, and from which batch size one GPU call beats one CPU core."""
+    from zkemail_rs_amd import _abi as A
+    import ctypes as C
+    lib, h = eng.lib, eng.h
+    email = wl.emails[0]
+    keep, args = eng._email_args(email)
+    out = np.zeros(1, dtype=A.RESULT_DTYPE)
+    ts = []
+    for i in range(calls + 20):
+        t0 = time.perf_counter()
+        rc = lib.zke_verify_email(h, *args, out.ctypes.data)
+        ts.append(time.perf_counter() - t0)
+        assert rc == 0
+    assert int(out[0]["status"]) == (0 if wl.inter[0].get("corrupt") is None else int(out[0]["status"]))
+    ts = np.sort(np.array(ts[20:])) * 1e6
+    res = {"entry": "zke_verify_email (a host batch of one: pack, H2D, three launches, D2H, wait)",
+           "gpu_p50": round(float(ts[len(ts) // 2]), 1), "gpu_p90": round(float(ts[int(len(ts) * 0.9)]), 1), "calls": calls}
+    sizes = [1, 2, 4, 8, 16, 32, 64, 128]
+    by_n = {}
+    for m in sizes:
+        if m > packed.n:
+            break
+        sub = A.PackedBatch(wl.emails[:m])
+        o = np.zeros(m, dtype=A.RESULT_DTYPE)
+        tt = []
+        for _ in range(40):
+            t0 = time.perf_counter()
+            assert lib.zke_verify_batch(h, C.byref(sub.c), o.ctypes.data, None) == 0
+            tt.append(time.perf_counter() - t0)
+        by_n[m] = round(float(np.median(tt[5:])) * 1e6, 1)
+    res["gpu_host_batch_us_by_n"] = by_n
+    if orc is not None and regex_inputs is None:
+        one = A.PackedBatch([email])
+        tt = []
+        for _ in range(200):
+            t0 = time.perf_counter()
+            orc.verify_batch(one, threads=1)
+            tt.append(time.perf_counter() - t0)
+        cpu = float(np.median(tt[10:])) * 1e6
+        res["oracle_one_core_us"] = round(cpu, 1)
+        res["gpu_beats_one_core_from_batch"] = next((m for m, us in by_n.items() if us < m * cpu), None)
+    return res
+
+
+def strong_scaling_main(args, cfgs, rank, local_rank, world, json_fd):
+    """BASELINE configs[3] as worded — ONE batch, sharded by cumulative bytes over the ranks (ShardedVerifier), the witnesses of
+    every e-mail all-gathered into batch order on every rank.  A step = the whole batch once."""
+    import torch
+    import torch.distributed as dist
+    import synth
+    import zkemail_rs_amd as z
+    from zkemail_rs_amd import _abi as A
+    from zkemail_rs_amd import distributed as D
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    cfg = dict(cfgs[args.workload])
+    if args.batch:
+        cfg["n"] = args.batch
+    # every rank generates the same batch from the same seed (a real job would read its shard): only the rank's range is kept
+    t0 = time.time()
+    wl = synth.make_workload_parallel(args.workload, seed=4242, **cfg) if cfg["n"] > 2048 else synth.make_workload(args.workload, seed=4242, **cfg)
+    gen_s = time.time() - t0
+    use_dist = world > 1
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+    eng = z.Engine(device=local_rank)
+    if use_dist:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    sv = D.ShardedVerifier(eng, rank=rank, world=world, device=dev)
+    sv.load(wl.emails)                                   # this rank's byte-balanced range, HBM-resident
+    for _ in range(max(1, args.warmup)):
+        sv.verify()
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wit = sv.verify()
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if use_dist:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    w = wit.cpu().numpy().view(A.WITNESS_DTYPE)
+    assert len(w) == cfg["n"] and (w["status"] == 0).all(), "strong-scaling batch: not every e-mail verified"
+    if rank == 0:
+        n = cfg["n"]
+        out = {"metric": "emails verified/sec (witness gen)", "value": round(n * args.steps / dt, 1), "unit": "emails/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+               "config": {"workload": f"{args.workload}: ONE batch of {n} e-mails, {cfg['body_len']} B bodies, RSA-{cfg.get('rsa_bits', 0)}, "
+                                      f"sharded by cumulative bytes over {world} rank(s)",
+                          "shard_bounds": sv.bounds, "collective": "one RCCL all_gather of the 72-B witnesses per step" if use_dist else "none"},
+               "hashed_body_GBps": round(wl.body_bytes * args.steps / dt / 1e9, 3), "workload_gen_s": round(gen_s, 2)}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()

@@ -22,7 +22,7 @@
 use std::ffi::CStr;
 use std::fmt;
 use std::ptr;
-use std::sync::{Mutex, OnceLock};
+use std::sync::OnceLock;
 
 use zkemail_amd_sys as sys;
 
@@ -209,20 +209,50 @@ fn regex_matches_of(info: &RegexInfo) -> Vec<String> {
     out
 }
 
-/// One engine per GPU: device workspaces, streams, registered DFA tables, the per-key Montgomery cache.
-/// Thread-compatible, as the C-ABI says: one engine per thread or external serialisation ([`default_engine`] wraps
-/// one in a `Mutex`).
+/// The default configuration (a zero-filled `zke_options` with the device set).
+pub fn default_options(device: i32) -> sys::zke_options {
+    sys::zke_options {
+        device,
+        slots: 0,
+        max_sig_rounds: 0,
+        disable_key_cache: 0,
+        host_threads: 0,
+        max_dfas: 0,
+        rsa_lane_groups: 0,
+        dfa_mapping: 0,
+        replay_graphs: 0,
+        enforce_expiry_x: 0,
+        canon_takes_verified_signature: 0,
+        canon_ignores_l: 0,
+        i_must_be_subdomain: 0,
+        b_removes_own_span_only: 0,
+        reserved0: 0,
+        now_unix: 0,
+        reserved: [0; 4],
+    }
+}
+
+/// One engine per GPU: submission slots (a stream, a workspace and a pinned staging image each), registered DFA
+/// tables, the per-key Montgomery cache.  Re-entrant, as the reference's functions are (core/src/circuits.rs:9): the
+/// C entry points take a slot by an atomic ticket and hold that slot's lock while they enqueue, so one `Engine` may be
+/// shared by any number of threads.
 pub struct Engine {
     raw: *mut sys::zke_engine,
 }
 
-// The handle owns device memory and a stream; it may move between threads, it must not be shared without a lock.
+// The handle owns device memory and streams; the C-ABI serialises what must be serialised (include/zkemail_amd.h, "Threading").
 unsafe impl Send for Engine {}
+unsafe impl Sync for Engine {}
 
 impl Engine {
-    /// `device`: HIP device ordinal, -1 = the current device.
+    /// `device`: HIP device ordinal, -1 = the current device.  Every other option at its default.
     pub fn new(device: i32) -> Result<Self, EngineError> {
-        let opt = sys::zke_options { device, reserved: [0; 7] };
+        Self::with_options(default_options(device))
+    }
+
+    /// An engine with explicit `zke_options` (ABI 0.3: submission slots, host threads, kernel variants and the
+    /// strictness flags — the readings of cfdkim that a maintainer with the crates at hand may want to flip).
+    pub fn with_options(opt: sys::zke_options) -> Result<Self, EngineError> {
         let mut raw: *mut sys::zke_engine = ptr::null_mut();
         // SAFETY: `opt` and `raw` outlive the call; the callee writes a handle or leaves null.
         let rc = unsafe { sys::zke_engine_create(&opt, &mut raw) };
@@ -240,7 +270,7 @@ impl Engine {
 
     /// Pre-size `slots` submission slots for batches of up to `max_n` e-mails / `max_raw_total` raw bytes
     /// (`zke_engine_reserve`): nothing is allocated in the submit path afterwards.
-    pub fn reserve(&mut self, max_n: u32, max_raw_total: u64, slots: u32, max_regex_parts: u32) -> Result<(), EngineError> {
+    pub fn reserve(&self, max_n: u32, max_raw_total: u64, slots: u32, max_regex_parts: u32) -> Result<(), EngineError> {
         // SAFETY: plain values.
         let rc = unsafe { sys::zke_engine_reserve(self.raw, max_n, max_raw_total, slots, max_regex_parts) };
         if rc != 0 {
@@ -250,7 +280,7 @@ impl Engine {
     }
 
     /// `verify_email` over a slice: one `Result` per e-mail, in order.  Never aborts the batch on a bad e-mail.
-    pub fn verify_emails(&mut self, emails: &[Email]) -> Result<Vec<Result<EmailVerifierOutput, Panic>>, EngineError> {
+    pub fn verify_emails(&self, emails: &[Email]) -> Result<Vec<Result<EmailVerifierOutput, Panic>>, EngineError> {
         if emails.is_empty() {
             return Ok(Vec::new());
         }
@@ -274,7 +304,7 @@ impl Engine {
     /// the same DFA pairs in the same order); the captures are per e-mail.  Each DFA pair is parsed and staged on
     /// the device once (`zke_dfa_register`), not once per e-mail as `core/src/regex.rs:32-33` does.
     pub fn verify_emails_with_regex(
-        &mut self,
+        &self,
         inputs: &[EmailWithRegex],
     ) -> Result<Vec<Result<EmailWithRegexVerifierOutput, Panic>>, EngineError> {
         if inputs.is_empty() {
@@ -282,7 +312,7 @@ impl Engine {
         }
         let empty: Vec<CompiledRegex> = Vec::new();
         let first = &inputs[0].regex_info;
-        let ids = |engine: &mut Engine, parts: &Option<Vec<CompiledRegex>>| -> Result<Vec<u32>, EngineError> {
+        let ids = |engine: &Engine, parts: &Option<Vec<CompiledRegex>>| -> Result<Vec<u32>, EngineError> {
             let mut v = Vec::new();
             for p in parts.as_ref().unwrap_or(&empty) {
                 let mut id = 0u32;
@@ -358,7 +388,7 @@ impl Engine {
     }
 
     /// One e-mail through the single-e-mail C entry point `zke_verify_email` (core/src/circuits.rs:9).
-    pub fn try_verify_email(&mut self, email: &Email) -> Result<Result<EmailVerifierOutput, Panic>, EngineError> {
+    pub fn try_verify_email(&self, email: &Email) -> Result<Result<EmailVerifierOutput, Panic>, EngineError> {
         let mut r = zeroed_result();
         let ext_null = email.external_inputs.iter().any(|x| x.value.is_none()) as u32;
         // SAFETY: the slices outlive the (synchronous) call; lengths are passed with them.
@@ -384,7 +414,7 @@ impl Engine {
 
     /// One `EmailWithRegex` through `zke_verify_email_with_regex` (core/src/circuits.rs:31).
     pub fn try_verify_email_with_regex(
-        &mut self,
+        &self,
         input: &EmailWithRegex,
     ) -> Result<Result<EmailWithRegexVerifierOutput, Panic>, EngineError> {
         // RegexInfo -> two zke_regex_part lists; the pointer tables live until the call returns
@@ -452,15 +482,15 @@ impl Drop for Engine {
 }
 
 /// The process-wide engine behind the two free functions (device: the current HIP device).
-pub fn default_engine() -> &'static Mutex<Engine> {
-    static ENGINE: OnceLock<Mutex<Engine>> = OnceLock::new();
-    ENGINE.get_or_init(|| Mutex::new(Engine::new(-1).expect("zkemail_amd: no usable GPU engine (there is no CPU fallback)")))
+/// Shared without a lock: the C-ABI's entry points are re-entrant (one submission slot per call in flight).
+pub fn default_engine() -> &'static Engine {
+    static ENGINE: OnceLock<Engine> = OnceLock::new();
+    ENGINE.get_or_init(|| Engine::new(-1).expect("zkemail_amd: no usable GPU engine (there is no CPU fallback)"))
 }
 
 /// `zkemail_core::verify_email` (core/src/circuits.rs:9-29): same signature, same panics.
 pub fn verify_email(email: &Email) -> EmailVerifierOutput {
-    let mut engine = default_engine().lock().unwrap_or_else(|p| p.into_inner());
-    match engine.try_verify_email(email) {
+    match default_engine().try_verify_email(email) {
         Err(e) => panic!("{e}"),
         Ok(Err(p)) => panic!("{p}"),
         Ok(Ok(out)) => out,
@@ -469,8 +499,7 @@ pub fn verify_email(email: &Email) -> EmailVerifierOutput {
 
 /// `zkemail_core::verify_email_with_regex` (core/src/circuits.rs:31-68): same signature, same panics.
 pub fn verify_email_with_regex(input: &EmailWithRegex) -> EmailWithRegexVerifierOutput {
-    let mut engine = default_engine().lock().unwrap_or_else(|p| p.into_inner());
-    match engine.try_verify_email_with_regex(input) {
+    match default_engine().try_verify_email_with_regex(input) {
         Err(e) => panic!("{e}"),
         Ok(Err(p)) => panic!("{p}"),
         Ok(Ok(out)) => out,

@@ -99,8 +99,25 @@ enum {
                                       which is exact for every other domain (d= itself is ASCII whenever it gets that far) */
   ZKE_D_U_MIME_CTYPE         = 67, /* a Content-Type value that decides the subpart walk holds bytes >= 0x80 or an RFC 2047 encoded word */
   ZKE_D_U_MIME_BOUNDARY      = 68, /* multipart boundary parameter folded across lines, or given only in an RFC 2231 form (boundary*, boundary*0) */
-  ZKE_D_U_MIME_DEPTH         = 69  /* multiparts nested more than 8 deep */
+  ZKE_D_U_MIME_DEPTH         = 69, /* multiparts nested more than 8 deep */
+  /* ZKE_DKIM_NOT_PASS, continued */
+  ZKE_D_SIG_EXPIRED          = 14, /* x= lies in the past (only with zke_options.enforce_expiry_x) */
+  /* ZKE_DFA_DECODE_FAIL: the section of the regex-automata dense-DFA blob at which dense::DFA::from_bytes would have
+   * given up (core/src/regex.rs:32-33).  70..79: the forward blob (verify_re.fwd); + 10: the reverse blob (verify_re.bwd).
+   * The sections the committed regex-automata blobs do not pin (unanchored start block, accelerators, quit set)
+   * have codes of their own so that the first real blob that fails says where the recalled layout is wrong. */
+  ZKE_D_DFA_LABEL            = 70, /* label / padding ("rust-regex-automata-dfa-dense\0", NUL-padded to 32 bytes) */
+  ZKE_D_DFA_ENDIAN_VERSION   = 71, /* endianness marker 0x0000FEFF, version 2, the unused word */
+  ZKE_D_DFA_FLAGS            = 72, /* the flags word */
+  ZKE_D_DFA_TRANSITIONS      = 73, /* state_len, stride2, byte classes, the transition table and its ids */
+  ZKE_D_DFA_START_TABLE      = 74, /* start kind, start-byte map, stride, pattern_len, universal starts, the start ids */
+  ZKE_D_DFA_MATCH_STATES     = 75, /* match-state slices, pattern_len, pattern ids */
+  ZKE_D_DFA_SPECIAL          = 76, /* the eight special-state bounds */
+  ZKE_D_DFA_ACCELS           = 77, /* accelerator count and records */
+  ZKE_D_DFA_QUITSET          = 78, /* the 256-bit quit set */
+  ZKE_D_DFA_UNREGISTERED     = 79  /* the part id names no registered pair (never registered, or unregistered since) */
 };
+#define ZKE_D_DFA_BWD_OFFSET 10u /* added to ZKE_D_DFA_LABEL .. ZKE_D_DFA_QUITSET when the reverse blob is the one that fails (80..88) */
 
 #define ZKE_MAX_HEADERS 256u   /* header fields per email the device parser tables hold */
 #define ZKE_MAX_TAGS    32u    /* tag-specs per DKIM-Signature */
@@ -187,23 +204,62 @@ typedef struct zke_debug_out {
                                                          0x200 key not cached yet, 0x400 cache slot taken, 0x800 not eligible */
 } zke_debug_out;
 
+/* Engine options.  A zero-filled struct (or NULL) is the default configuration: every field is phrased so that 0 means
+ * "what the engine does by default".  ABI 0.3: the fields have names (0.2 kept them in reserved[]). */
 typedef struct zke_options {
-  int32_t  device;        /* HIP device ordinal; -1 = current */
-  /* reserved[0]: how many same-domain DKIM-Signature headers are tried per e-mail, in file order, until one passes —
-   *              cfdkim tries them all; default 16, at most ZKE_MAX_HEADERS.  The first is tried in the batch's three
-   *              launches, later ones inside the last of them by the e-mail's own wave (both entry points alike, nothing is
-   *              read back).  An e-mail with more failing candidates reports ZKE_UNSUPPORTED / ZKE_D_U_TOO_MANY_SIGS.
-   * reserved[1], reserved[2]: unused (0).
-   * reserved[3]: non-zero disables the per-key Montgomery-constant cache of the RSA kernels.  Others: 0. */
-  uint32_t reserved[7];
+  int32_t  device;              /* HIP device ordinal; -1 = the calling thread's current device.  NOTE: 0 is device 0. */
+  uint32_t slots;               /* submission slots created with the engine (0 = 1); zke_engine_reserve can raise it later */
+  uint32_t max_sig_rounds;      /* same-domain DKIM-Signature headers tried per e-mail, in file order, until one passes — cfdkim
+                                   tries them all; 0 = 16, at most ZKE_MAX_HEADERS.  The first is tried in the batch's three
+                                   launches, later ones inside the last of them by the e-mail's own wave.  An e-mail with more
+                                   failing candidates reports ZKE_UNSUPPORTED / ZKE_D_U_TOO_MANY_SIGS. */
+  uint32_t disable_key_cache;   /* 1: no per-key Montgomery-constant cache (R^2 mod n recomputed per signature) */
+  uint32_t host_threads;        /* worker threads that copy host-entry batches into pinned staging memory (0 = 4; 1 = the caller's
+                                   thread alone).  zke_verify_batch[_async] only. */
+  uint32_t max_dfas;            /* DFA pairs the registry holds before it evicts pairs that zke_verify_email_with_regex registered
+                                   on its own (0 = 4096) */
+  /* kernel variants (0 = chosen by batch size; the parity tests force each) */
+  uint32_t rsa_lane_groups;     /* 1: never the four- / eight-lanes-per-signature RSA routines; 2: always */
+  uint32_t dfa_mapping;         /* 1: one e-mail per lane for every regex part; 2: one e-mail per wave for every part */
+  uint32_t replay_graphs;       /* 1: zke_verify_batch_device replays a captured hipGraph when a slot sees the same descriptor
+                                   again (measured slower than plain launches on MI355X: DESIGN.md §5) */
+  /* Strictness flags: behaviours of the reference's un-vendored crates that could not be verified offline (SURVEY.md
+   * Appendix B "open questions").  0 = this engine's reading of cfdkim@75af99fb; 1 = the other reading.  Each
+   * flag switches ONE named site in the device front end (csrc/parse.hip.h, ZKE_STRICT_*) and the same site in the CPU
+   * oracle (oracle/zke_oracle.c), so a maintainer with the Rust crates at hand flips a field, not a kernel. */
+  uint32_t enforce_expiry_x;             /* 1: a signature whose x= tag lies before `now_unix` fails (ZKE_D_SIG_EXPIRED), as
+                                            cloudflare/dkim's validate_header does; 0: x= is ignored (a zkVM guest has no clock) */
+  uint32_t canon_takes_verified_signature; /* canonicalize_signed_email (core/src/circuits.rs:34-35) — 0: the FIRST DKIM-Signature
+                                            header of the e-mail, whatever its d=; 1: the signature verify_dkim accepted */
+  uint32_t canon_ignores_l;              /* 0: canonicalize_signed_email truncates the canonical body to l=, as the verify path
+                                            does; 1: it returns the whole canonical body */
+  uint32_t i_must_be_subdomain;          /* i= check — 0: i= ends with d= (a plain suffix test); 1: the domain of i= (behind its
+                                            last '@') equals d= or ends with "." d=, case-insensitively (RFC 6376 §3.5) */
+  uint32_t b_removes_own_span_only;      /* 0: the raw b= value is removed wherever it occurs in the header (String::replace);
+                                            1: only the b= tag's own span is emptied */
+  uint32_t reserved0;
+  uint64_t now_unix;            /* the time x= is compared with (enforce_expiry_x); 0 = the host clock at submission */
+  uint64_t reserved[4];         /* 0 */
 } zke_options;
+
+/* bits of the strictness mask the kernels and the oracle take (one per flag above, same order) */
+#define ZKE_STRICT_EXPIRY_X        1u
+#define ZKE_STRICT_CANON_VERIFIED  2u
+#define ZKE_STRICT_CANON_IGNORES_L 4u
+#define ZKE_STRICT_I_SUBDOMAIN     8u
+#define ZKE_STRICT_B_OWN_SPAN      16u
 
 typedef struct zke_engine zke_engine;
 
-/* Per-kernel device time of the last batch, microseconds (HIP events on the engine's stream). */
+/* Device time of one batch's launches, microseconds (HIP events on the stream the batch ran on; zke_set_timing). */
 typedef struct zke_timings {
-  float parse_us, canon_body_us, sha_us, rsa_us, qp_us, dfa_us, finalize_us, total_us;
-  float h2d_us, d2h_us;
+  float front_end_us;     /* parse_kernel: header split, key decode, tag lists, header-hash preimage, body canonicalisation */
+  float hash_modexp_us;   /* hash_modexp_kernel: the SHA-256 groups beside the RSA roles (one launch) */
+  float ed_verdict_us;    /* ed_verdict_kernel: Ed25519 stage, verdicts, later signature rounds */
+  float regex_prep_us;    /* verify_email_with_regex: canonicalize_signed_email pass + QP soft-break removal */
+  float dfa_us;           /* ... the DFA launches and the regex verdict */
+  float total_us;         /* first launch to last launch (copies excluded) */
+  float h2d_us, d2h_us;   /* host entry only: the packed input image in, the records out */
 } zke_timings;
 
 /* All functions return 0 on success, or a negative code if the CALL failed (bad
@@ -213,31 +269,70 @@ typedef struct zke_timings {
 #define ZKE_E_NOMEM   (-3)
 #define ZKE_E_DFA     (-4)
 
+/* Process-wide set-up, optional.  HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and reads the
+ * variable once, when the runtime initialises; every submission slot wants a queue of its own, and MI355X runs 24 queues of a
+ * process without time-slicing them.  zke_process_init(q) exports GPU_MAX_HW_QUEUES = q (0 = 23: 22 slots + the
+ * null stream) unless the variable is already set.  It has an effect only before the process's first HIP call: call it first
+ * thing in main().  zke_engine_create calls zke_process_init(0) itself, which covers hosts whose first HIP call is that
+ * one; a host that has used HIP before (a framework, another library) keeps the pool it has and should call this itself,
+ * earlier.  Nothing else in this library touches the process environment, and nothing runs at load time. */
+int zke_process_init(uint32_t hw_queues);
+
 int zke_engine_create(const zke_options* opt, zke_engine** out);
 void zke_engine_destroy(zke_engine* e);
+/* The message of the last failed call on this engine by the calling thread ("" if none). */
 const char* zke_last_error(const zke_engine* e);
 
-/* One engine per GPU.  An engine owns `slots` submission slots — a stream and a private workspace each — so that many
- * batches can be in flight at once; what batches share (the per-key Montgomery constants of the RSA kernels, the
- * registered DFA tables, kernel attributes) exists once per engine.  zke_engine_create makes one slot.
+/* Threading.  The reference's two functions are re-entrant (core/src/circuits.rs:9: no state between calls), and so are
+ * the entry points here: zke_verify_batch, zke_verify_batch_async / zke_batch_wait, zke_verify_batch_device,
+ * zke_verify_email, zke_verify_email_with_regex and zke_dfa_register may be called from any number of host threads on ONE
+ * engine at once.  Each call takes the next submission slot (an atomic ticket) and holds that slot's lock while it
+ * enqueues; everything a call needs lives in its slot.  zke_engine_reserve, zke_dfa_unregister and zke_engine_destroy
+ * are exclusive: they wait for the submissions in progress and hold new ones off. */
+
+/* One engine per GPU.  An engine owns `slots` submission slots — a stream, a private workspace and (host entry) a pinned
+ * staging image each — so that many batches can be in flight at once; what batches share (the per-key Montgomery constants
+ * of the RSA kernels, the registered DFA tables, kernel attributes) exists once per engine.
  * zke_engine_reserve(e, max_n, max_raw_total, slots, max_regex_parts) raises the slot count to `slots` (1..64) and sizes
  * every slot's workspace for batches of up to max_n e-mails / max_raw_total raw bytes (max_regex_parts > 0: the
  * verify_email_with_regex buffers too), so that no allocation happens in the submit path afterwards.  A larger batch
  * still works: its slot grows (one synchronising reallocation). */
 int zke_engine_reserve(zke_engine* e, uint32_t max_n, uint64_t max_raw_total, uint32_t slots, uint32_t max_regex_parts);
+/* The same for the host entry's staging: every slot's pinned input image and record buffer (and their HBM twins) are sized
+ * for batches of up to max_n e-mails whose inputs — raw e-mails + from_domains + keys (+ captures) — total max_input_bytes.
+ * Pinned memory is a host resource (S slots x image bytes): a caller that only uses zke_verify_batch_device never pays it,
+ * and without this call a slot's staging comes into being with its first host batch. */
+int zke_engine_reserve_host(zke_engine* e, uint32_t max_n, uint64_t max_input_bytes);
 
 /* Parse one regex-automata 0.4 dense-DFA pair once (replaces the per-email
  * dense::DFA::from_bytes of core/src/regex.rs:32-33), validate it and stage a repacked
  * transition table on the device.  Accepts unaligned input, so the align_slice shim
  * (core/src/regex.rs:5-13) is unnecessary.  A blob that from_bytes would reject still
- * gets an id; emails using it report ZKE_DFA_DECODE_FAIL. */
+ * gets an id; emails using it report ZKE_DFA_DECODE_FAIL with the failing section as `detail` (ZKE_D_DFA_*).
+ * An equal pair registered again gets its old id (the registry is keyed by a hash of the pair). */
 int zke_dfa_register(zke_engine* e, const uint8_t* fwd, size_t fwd_len,
                      const uint8_t* bwd, size_t bwd_len, uint32_t* out_id);
+/* *detail = 0 when both blobs of pair `id` deserialise, else the ZKE_D_DFA_* section at which from_bytes gives up. */
+int zke_dfa_status(zke_engine* e, uint32_t id, uint32_t* detail);
+/* Drop a registered pair and free its tables (waits for the batches in flight).  The id may be given out again. */
+int zke_dfa_unregister(zke_engine* e, uint32_t id);
 
-/* Host-memory batch: copies inputs to HBM, runs the device pipeline, copies n records back. */
+/* Host-memory batch — what a drop-in caller has: `&[Email]` in RAM (core/src/circuits.rs:9 takes a host-resident &Email,
+ * built at helpers/src/generator.rs:40-45).  The offsets, key types and the three blobs are packed into ONE image in the
+ * slot's pinned staging buffer (by `host_threads` workers for large batches), cross PCIe as ONE copy on the slot's
+ * stream, the three launches follow, and the n records come back as one copy into pinned memory.
+ *   zke_verify_batch_async  returns as soon as everything is enqueued; `in` has been read completely (the caller may reuse
+ *                           its buffers), `out` must stay valid until zke_batch_wait(e, *ticket) has returned.  With S slots
+ *                           reserved, S batches are in flight; a slot whose previous batch was never waited for completes it
+ *                           (its records are delivered) before it is reused.
+ *   zke_batch_wait          blocks until that batch's records are in `out`.  Waiting twice, or for a ticket a later batch of
+ *                           the same slot has already retired, returns 0 at once.
+ *   zke_verify_batch        = async + wait; `dbg` != NULL additionally copies the parity intermediates back (tests). */
 int zke_verify_batch(zke_engine* e, const zke_batch* in, zke_result* out, zke_debug_out* dbg);
+int zke_verify_batch_async(zke_engine* e, const zke_batch* in, zke_result* out, uint64_t* ticket);
+int zke_batch_wait(zke_engine* e, uint64_t ticket);
 
-/* Device-resident batch: every pointer in `in` and `out_dev` is device memory;
+/* Device-resident batch: every pointer in `in` and `out_dev` is device memory (the part-id lists stay host arrays);
  * `raw_total`, `domain_total`, `key_total` are the blob sizes (the CSR tails), which the
  * host needs for workspace sizing without a device read.  Takes the engine's next submission slot (round-robin),
  * enqueues on `stream` (a hipStream_t; NULL = that slot's own stream) and returns without synchronising: with S slots
@@ -251,9 +346,11 @@ int zke_engine_sync(zke_engine* e);
  * after this call runs behind every batch submitted so far, on whichever slot or stream it went.  For a consumer of the
  * result records that lives on a stream of its own (a copy, a collective): it can be enqueued while the batches still run. */
 int zke_engine_join(zke_engine* e, void* stream);
-int zke_get_timings(zke_engine* e, zke_timings* t);                          /* the slot of the most recent batch */
-int zke_get_slot_timings(zke_engine* e, uint32_t slot, zke_timings* t);     /* the last batch that ran in `slot` */
-/* Enable per-kernel HIP-event timing (adds event records between kernels). */
+/* Timings of the last batch that ran in `slot` / in the slot used most recently.  A slot that has not run a timed batch
+ * reports all zeros. */
+int zke_get_timings(zke_engine* e, zke_timings* t);
+int zke_get_slot_timings(zke_engine* e, uint32_t slot, zke_timings* t);
+/* Enable per-launch HIP-event timing (adds event records between the launches). */
 int zke_set_timing(zke_engine* e, int enabled);
 
 /* Single-email wrappers over a batch of one (config 1 / API-shape parity): the two functions of the reference,
@@ -276,7 +373,8 @@ typedef struct zke_regex_part {
 } zke_regex_part;
 
 /* Registers the DFA pairs it has not seen before (zke_dfa_register returns the old id for an equal pair), so calling
- * this per e-mail with the same regex_config parses every table once, not once per e-mail as core/src/regex.rs:32-33. */
+ * this per e-mail with the same regex_config parses every table once, not once per e-mail as core/src/regex.rs:32-33.
+ * Pairs registered this way are the ones the registry evicts (least recently used first) when it is full. */
 int zke_verify_email_with_regex(zke_engine* e, const uint8_t* raw, size_t raw_len,
                                 const char* from_domain, size_t domain_len,
                                 const uint8_t* key, size_t key_len, uint32_t key_type,
@@ -317,8 +415,9 @@ int zke_abi_encode(const uint8_t* from_domain_hash /*[32]*/, const uint8_t* publ
                    uint32_t with_matches, const uint8_t* const* matches, const size_t* match_lens, uint32_t n_matches,
                    uint8_t* out, size_t out_cap, size_t* out_len);
 
-/* Library / build identification. */
+/* Library / build identification.  zke_abi_version() = 3 for this header (struct layouts and entry points of ABI 0.3). */
 const char* zke_version(void);
+uint32_t zke_abi_version(void);
 /* 1 if a HIP device is usable from this process, else 0 (never falls back to a CPU path). */
 int zke_device_available(void);
 

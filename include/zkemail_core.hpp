@@ -102,7 +102,11 @@ class Engine {
   explicit Engine(int device = -1) {
     zke_options o{};
     o.device = device;
-    if (int r = zke_engine_create(&o, &e_)) throw EngineError("zke_engine_create failed: " + std::to_string(r));
+    if (int r = zke_engine_create(&o, &e_)) throw EngineError("zke_engine_create failed: " + std::to_string(r) + " " + zke_last_error(nullptr));
+  }
+  // every field of zke_options by name (ABI 0.3): slots, host threads, kernel variants, the strictness flags
+  explicit Engine(const zke_options& o) {
+    if (int r = zke_engine_create(&o, &e_)) throw EngineError("zke_engine_create failed: " + std::to_string(r) + " " + zke_last_error(nullptr));
   }
   ~Engine() { zke_engine_destroy(e_); }
   Engine(const Engine&) = delete;

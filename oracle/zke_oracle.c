@@ -676,8 +676,9 @@ static int tag_eq(const taglist_t* tl, const tag_t* t, const char* lit) {
   return t->val_len == l && memcmp(tl->tagbuf + t->val_off, lit, l) == 0;
 }
 
-/* cfdkim validate_header (RFC 6376 §6.1.1); the zkVM fork cannot read a clock, x= is not enforced */
-static int validate_header(const uint8_t* s, size_t n, taglist_t* tl) {
+/* cfdkim validate_header (RFC 6376 §6.1.1).  `strict`: ZKE_STRICT_* — the readings of cfdkim that could not be verified offline
+ * (zke_options' strictness flags); each is one named site here and the same site in csrc/parse.hip.h. */
+static int validate_header(const uint8_t* s, size_t n, taglist_t* tl, uint32_t strict, uint64_t now) {
   int overflow = 0;
   if (parse_tag_list(s, n, tl, &overflow)) return ZKE_D_SIG_SYNTAX;
   if (overflow == 1) return ZKE_D_U_TOO_MANY_TAGS;
@@ -689,9 +690,22 @@ static int validate_header(const uint8_t* s, size_t n, taglist_t* tl) {
   const tag_t* ti = get_tag(tl, s, "i");
   const tag_t* td = get_tag(tl, s, "d");
   if (ti) {
-    if (ti->val_len < td->val_len ||
-        memcmp(tl->tagbuf + ti->val_off + ti->val_len - td->val_len, tl->tagbuf + td->val_off, td->val_len))
-      return ZKE_D_DOMAIN_MISMATCH;
+    /* STRICTNESS SITE i_must_be_subdomain.  Default: user.ends_with(signing_domain), a plain suffix test on the bytes.
+     * ZKE_STRICT_I_SUBDOMAIN: the domain of i= (behind its last '@'; the whole value without one) equals d= or ends with
+     * "." d=, ASCII case folded (RFC 6376 §3.5). */
+    const uint8_t* iv = tl->tagbuf + ti->val_off;
+    const uint8_t* dv = tl->tagbuf + td->val_off;
+    if (!(strict & ZKE_STRICT_I_SUBDOMAIN)) {
+      if (ti->val_len < td->val_len || memcmp(iv + ti->val_len - td->val_len, dv, td->val_len)) return ZKE_D_DOMAIN_MISMATCH;
+    } else {
+      size_t ds = 0;
+      for (size_t k = 0; k < ti->val_len; k++) if (iv[k] == '@') ds = k + 1;
+      const size_t il = ti->val_len - ds;
+      if (il < td->val_len) return ZKE_D_DOMAIN_MISMATCH;
+      for (size_t k = 0; k < td->val_len; k++)
+        if (lower(iv[ti->val_len - td->val_len + k]) != lower(dv[k])) return ZKE_D_DOMAIN_MISMATCH;
+      if (il > td->val_len && iv[ti->val_len - td->val_len - 1] != '.') return ZKE_D_DOMAIN_MISMATCH;
+    }
   }
   {
     const tag_t* th = get_tag(tl, s, "h");
@@ -709,6 +723,27 @@ static int validate_header(const uint8_t* s, size_t n, taglist_t* tl) {
   }
   const tag_t* tq = get_tag(tl, s, "q");
   if (tq && !tag_eq(tl, tq, "dns/txt")) return ZKE_D_BAD_QUERY_METHOD;
+  const tag_t* tx = (strict & ZKE_STRICT_EXPIRY_X) ? get_tag(tl, s, "x") : NULL;
+  if (tx) {
+    /* STRICTNESS SITE enforce_expiry_x.  Default: x= is ignored — a zkVM guest has no clock.  ZKE_STRICT_EXPIRY_X:
+     * cloudflare/dkim's rule — x= parsed as i64 (str::parse: optional sign, digits, no overflow; anything else counts as
+     * 0), fifteen minutes of drift allowed, expired when now > x + 900. */
+    const uint8_t* xs = tl->tagbuf + tx->val_off;
+    size_t k = 0, xn = tx->val_len;
+    int neg = 0, okx = xn > 0;
+    if (okx && (xs[0] == '+' || xs[0] == '-')) { neg = xs[0] == '-'; k = 1; okx = xn > 1; }
+    uint64_t mag = 0;
+    const uint64_t lim = neg ? (1ull << 63) : (1ull << 63) - 1;
+    for (; okx && k < xn; k++) {
+      if (xs[k] < '0' || xs[k] > '9') { okx = 0; break; }
+      const uint64_t dgt = (uint64_t)(xs[k] - '0');
+      if (mag > (lim - dgt) / 10) { okx = 0; break; }
+      mag = mag * 10 + dgt;
+    }
+    const int64_t x = okx ? (neg ? (int64_t)(0 - mag) : (int64_t)mag) : 0;
+    const int64_t deadline = x > INT64_MAX - 900 ? INT64_MAX : x + 900;
+    if ((int64_t)now > deadline) return ZKE_D_SIG_EXPIRED;
+  }
   return 0;
 }
 
@@ -811,7 +846,7 @@ static void find_body(parsed_t* pm) {
 }
 
 /* cfdkim hash::select_headers + compute_headers_hash preimage */
-static size_t build_preimage(const parsed_t* pm, const uint8_t* sv, size_t svl, const taglist_t* tl, int relaxed, uint8_t* out) {
+static size_t build_preimage(const parsed_t* pm, const uint8_t* sv, size_t svl, const taglist_t* tl, int relaxed, uint8_t* out, uint32_t strict) {
   size_t o = 0;
   const tag_t* th = get_tag(tl, sv, "h");
   const uint8_t* h = tl->tagbuf + th->val_off;
@@ -846,8 +881,13 @@ static size_t build_preimage(const parsed_t* pm, const uint8_t* sv, size_t svl, 
   size_t bl = tb->raw_e - tb->raw_s;
   uint8_t* tmp = (uint8_t*)malloc(svl + 1);
   size_t tn = 0;
+  /* STRICTNESS SITE b_removes_own_span_only.  Default: String::replace — every occurrence of the raw b= value goes.
+   * ZKE_STRICT_B_OWN_SPAN: only the tag's own span is emptied. */
   if (bl == 0) {
     memcpy(tmp, sv, svl); tn = svl;
+  } else if (strict & ZKE_STRICT_B_OWN_SPAN) {
+    memcpy(tmp, sv, tb->raw_s); tn = tb->raw_s;
+    memcpy(tmp + tn, sv + tb->raw_e, svl - tb->raw_e); tn += svl - tb->raw_e;
   } else {
     for (size_t i = 0; i < svl;) {
       if (i + bl <= svl && memcmp(sv + i, sv + tb->raw_s, bl) == 0) { i += bl; continue; }
@@ -879,7 +919,7 @@ static int parse_usize(const uint8_t* s, size_t n, uint64_t* out) {
 /* c= / a= / l= handling + both canonicalisations for one validated signature.
  * returns 0 or a ZKE_D_* detail */
 /* *algo_unsupported (historic name) = 1 when a=ed25519-sha256, 0 for the rsa-* algorithms */
-static int canon_for_sig(const parsed_t* pm, const uint8_t* sv, size_t svl, const taglist_t* tl, canon_t* c, int* algo_unsupported) {
+static int canon_for_sig(const parsed_t* pm, const uint8_t* sv, size_t svl, const taglist_t* tl, canon_t* c, int* algo_unsupported, uint32_t strict) {
   const tag_t* tc = get_tag(tl, sv, "c");
   c->hdr_relaxed = c->body_relaxed = 0;
   if (tc) {
@@ -907,7 +947,7 @@ static int canon_for_sig(const parsed_t* pm, const uint8_t* sv, size_t svl, cons
     c->has_len = 1;
     if (c->len_tag < c->cbody_len) c->cbody_len = (size_t)c->len_tag;
   }
-  c->preimage_len = build_preimage(pm, sv, svl, tl, c->hdr_relaxed, c->preimage);
+  c->preimage_len = build_preimage(pm, sv, svl, tl, c->hdr_relaxed, c->preimage, strict);
   return 0;
 }
 
@@ -946,32 +986,38 @@ typedef struct {
 
 static uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 
+/* 0 when the blob deserialises, else the section at which from_bytes gives up (ZKE_D_DFA_LABEL .. ZKE_D_DFA_QUITSET): the
+ * `detail` of ZKE_DFA_DECODE_FAIL, the same section names as the engine's parser (csrc/dfa_registry.hip.h) */
 static int dfa_parse(const uint8_t* b, size_t n, dfa_t* d) {
+  int sec = ZKE_D_DFA_LABEL;
   static const char LABEL[] = "rust-regex-automata-dfa-dense";
   memset(d, 0, sizeof *d);
   size_t p = 0;
   while (p < n && p < 7 && b[p] == 0) p++; /* wire::skip_initial_padding */
-#define NEED(k) do { if (n - p < (size_t)(k)) return -1; } while (0)
+#define NEED(k) do { if (n - p < (size_t)(k)) return sec; } while (0)
   NEED(32);
-  if (memcmp(b + p, LABEL, 29) || b[p + 29] != 0) return -1;
+  if (memcmp(b + p, LABEL, 29) || b[p + 29] != 0) return sec;
   p += 32;
-  NEED(4); if (rd32(b + p) != 0xFEFF) return -1; p += 4;
-  NEED(4); if (rd32(b + p) != 2) return -1; p += 4;
+  sec = ZKE_D_DFA_ENDIAN_VERSION;
+  NEED(4); if (rd32(b + p) != 0xFEFF) return sec; p += 4;
+  NEED(4); if (rd32(b + p) != 2) return sec; p += 4;
   NEED(4); p += 4; /* unused */
   /* Flags::from_bytes: ONE u32 bit set — bit 0 has_empty, bit 1 is_utf8, bit 2 is_always_start_anchored (other bits ignored).
    * SURVEY Appendix A.3 recalled three u32s here; blobs written by regex-automata itself (tests/golden/regex_automata_*.dfa)
    * show one, and everything behind it as A.3 has it. */
+  sec = ZKE_D_DFA_FLAGS;
   NEED(4);
   { uint32_t fl = rd32(b + p); d->has_empty = fl & 1u; d->is_utf8 = (fl >> 1) & 1u; d->always_anchored = (fl >> 2) & 1u; }
   p += 4;
   /* transition table */
+  sec = ZKE_D_DFA_TRANSITIONS;
   NEED(8 + 256);
   d->state_len = rd32(b + p); d->stride2 = rd32(b + p + 4); p += 8;
   memcpy(d->classes, b + p, 256); p += 256;
-  if (d->stride2 < 1 || d->stride2 > 9) return -1;
+  if (d->stride2 < 1 || d->stride2 > 9) return sec;
   d->alphabet_len = (uint32_t)d->classes[255] + 2;
-  if (d->alphabet_len > (1u << d->stride2)) return -1;
-  if (d->state_len > (1u << 26)) return -1;
+  if (d->alphabet_len > (1u << d->stride2)) return sec;
+  if (d->state_len > (1u << 26)) return sec;
   d->table_len = (size_t)d->state_len << d->stride2;
   NEED(d->table_len * 4);
   d->table = (uint32_t*)malloc(d->table_len * 4 + 4);
@@ -981,58 +1027,63 @@ static int dfa_parse(const uint8_t* b, size_t n, dfa_t* d) {
   for (size_t s = 0; s < d->state_len; s++)
     for (uint32_t c = 0; c < d->alphabet_len; c++) {
       uint32_t id = d->table[(s << d->stride2) + c];
-      if (id >= d->table_len || (id & (stride - 1))) return -1; /* tt.is_valid */
+      if (id >= d->table_len || (id & (stride - 1))) return sec; /* tt.is_valid */
     }
   /* start table */
+  sec = ZKE_D_DFA_START_TABLE;
   NEED(4 + 256 + 16);
   d->start_kind = rd32(b + p); p += 4;
-  if (d->start_kind > 2) return -1;
+  if (d->start_kind > 2) return sec;
   memcpy(d->start_map, b + p, 256); p += 256;
-  for (int i = 0; i < 256; i++) if (d->start_map[i] >= 6) return -1;
+  for (int i = 0; i < 256; i++) if (d->start_map[i] >= 6) return sec;
   d->start_stride = rd32(b + p); p += 4;
-  if (d->start_stride != 6) return -1;
+  if (d->start_stride != 6) return sec;
   d->start_pattern_len = rd32(b + p); p += 4;
   p += 8; /* universal unanchored / anchored start (not needed for search) */
   size_t npat = d->start_pattern_len == 0xFFFFFFFFu ? 0 : d->start_pattern_len;
-  if (npat > (1u << 20)) return -1;
+  if (npat > (1u << 20)) return sec;
   d->starts_len = 2 * 6 + 6 * npat;
   NEED(d->starts_len * 4);
   d->starts = (uint32_t*)malloc(d->starts_len * 4);
   for (size_t i = 0; i < d->starts_len; i++) {
     d->starts[i] = rd32(b + p + 4 * i);
-    if (d->starts[i] >= d->table_len || (d->starts[i] & (stride - 1))) return -1;
+    if (d->starts[i] >= d->table_len || (d->starts[i] & (stride - 1))) return sec;
   }
   p += d->starts_len * 4;
   /* match states */
+  sec = ZKE_D_DFA_MATCH_STATES;
   NEED(4);
   uint32_t ms_len = rd32(b + p); p += 4;
-  if (ms_len > d->state_len) return -1;
+  if (ms_len > d->state_len) return sec;
   NEED((size_t)ms_len * 8 + 8);
   p += (size_t)ms_len * 8;
   p += 4; /* pattern_len */
   uint32_t idlen = rd32(b + p); p += 4;
-  if (idlen > (1u << 24)) return -1;
+  if (idlen > (1u << 24)) return sec;
   NEED((size_t)idlen * 4);
   p += (size_t)idlen * 4;
   /* special */
+  sec = ZKE_D_DFA_SPECIAL;
   NEED(32);
   d->sp_max = rd32(b + p); d->quit_id = rd32(b + p + 4); d->min_match = rd32(b + p + 8); d->max_match = rd32(b + p + 12);
   d->min_accel = rd32(b + p + 16); d->max_accel = rd32(b + p + 20); d->min_start = rd32(b + p + 24); d->max_start = rd32(b + p + 28);
   p += 32;
-  if (d->min_match > d->max_match || d->min_accel > d->max_accel || d->min_start > d->max_start) return -1;
-  if ((d->min_match == 0) != (d->max_match == 0)) return -1;
-  if (d->max_match > d->sp_max || d->max_accel > d->sp_max || d->max_start > d->sp_max) return -1;
-  if (d->sp_max >= d->table_len && d->table_len) return -1;
+  if (d->min_match > d->max_match || d->min_accel > d->max_accel || d->min_start > d->max_start) return sec;
+  if ((d->min_match == 0) != (d->max_match == 0)) return sec;
+  if (d->max_match > d->sp_max || d->max_accel > d->sp_max || d->max_start > d->sp_max) return sec;
+  if (d->sp_max >= d->table_len && d->table_len) return sec;
   {
     uint32_t nm = d->max_match ? ((d->max_match - d->min_match) >> d->stride2) + 1 : 0;
-    if (nm != ms_len) return -1;
+    if (nm != ms_len) return ZKE_D_DFA_MATCH_STATES;
   }
   /* accelerators: u32 count then 8 bytes each */
+  sec = ZKE_D_DFA_ACCELS;
   NEED(4);
   uint32_t acc = rd32(b + p); p += 4;
-  if (acc > d->state_len) return -1;
+  if (acc > d->state_len) return sec;
   NEED((size_t)acc * 8);
   p += (size_t)acc * 8;
+  sec = ZKE_D_DFA_QUITSET;
   NEED(32);
   memcpy(d->quitset, b + p, 32); p += 32;
   for (int i = 0; i < 32; i++) if (d->quitset[i]) d->quitset_nonempty = 1;
@@ -1130,7 +1181,7 @@ static int dfa_search_fwd(const dfa_t* d, const uint8_t* hay, size_t hlen, size_
   }
   return 1;
 }
-typedef struct { dfa_t fwd, rev; } regex_t_;
+typedef struct { dfa_t fwd, rev; uint32_t detail; } regex_t_;      /* detail: 0, or the ZKE_D_DFA_* section that does not parse */
 /* dfa::regex::Regex::try_search */
 static int regex_search(const regex_t_* re, const uint8_t* hay, size_t hlen, size_t start, size_t end, size_t* ms, size_t* me) {
   size_t e;
@@ -1155,12 +1206,22 @@ int zko_dfa_register(const uint8_t* fwd, size_t fwd_len, const uint8_t* bwd, siz
   pthread_mutex_lock(&g_re_mu);
   if (g_nre >= MAX_DFAS) { pthread_mutex_unlock(&g_re_mu); return -1; }
   regex_t_* re = (regex_t_*)calloc(1, sizeof *re);
-  dfa_parse(fwd, fwd_len, &re->fwd);
-  dfa_parse(bwd, bwd_len, &re->rev);
+  int det = dfa_parse(fwd, fwd_len, &re->fwd);
+  if (!det) { det = dfa_parse(bwd, bwd_len, &re->rev); if (det) det += ZKE_D_DFA_BWD_OFFSET; }
+  else dfa_parse(bwd, bwd_len, &re->rev);
+  re->detail = (uint32_t)det;
   g_re[g_nre] = re;
   *out_id = g_nre++;
   pthread_mutex_unlock(&g_re_mu);
   return 0;
+}
+/* 0, or the section at which the pair does not deserialise (the engine's zke_dfa_status); -1: no such id */
+long zko_dfa_status(uint32_t id) {
+  long r = -1;
+  pthread_mutex_lock(&g_re_mu);
+  if (id < g_nre) r = (long)g_re[id]->detail;
+  pthread_mutex_unlock(&g_re_mu);
+  return r;
 }
 void zko_dfa_reset(void) {
   pthread_mutex_lock(&g_re_mu);
@@ -1235,7 +1296,8 @@ static int process_parts(const zke_batch* in, uint32_t i, const uint32_t* ids, u
     uint32_t id = ids[k];
     out->regex_part = pbase + k;
     out->match_count = 0; out->match_start = 0; out->match_end = 0;
-    if (id >= g_nre || !g_re[id]->fwd.valid || !g_re[id]->rev.valid) { *decode_fail = 1; return ZKE_D_NONE; }
+    if (id >= g_nre) { *decode_fail = ZKE_D_DFA_UNREGISTERED; return ZKE_D_NONE; }
+    if (g_re[id]->detail) { *decode_fail = (int)g_re[id]->detail; return ZKE_D_NONE; }
     uint32_t sp[4];
     long n = zko_regex_find_iter(id, hay, hlen, sp, 2);
     if (n == -1) return ZKE_D_RE_QUIT;
@@ -1289,7 +1351,7 @@ static void dbg_copy(uint8_t* base, size_t stride, uint32_t i, const uint8_t* sr
   memcpy(base + (size_t)i * stride, src, n);
 }
 
-static void verify_one(const zke_batch* in, uint32_t i, zke_result* out, zke_debug_out* dbg, scratch_t* sc) {
+static void verify_one(const zke_batch* in, uint32_t i, zke_result* out, zke_debug_out* dbg, scratch_t* sc, uint32_t strict, uint64_t now) {
   memset(out, 0, sizeof *out);
   out->regex_part = 0xFFFFFFFFu;
   const uint8_t* raw = in->raw_blob + in->raw_off[i];
@@ -1347,20 +1409,21 @@ static void verify_one(const zke_batch* in, uint32_t i, zke_result* out, zke_deb
   canon_t cn; cn.preimage = sc->preimage; cn.cbody = sc->cbody;
   uint32_t last_err = ZKE_D_NEUTRAL, unsupported = 0, sig_ix = 0;
   int passed = 0;
+  const uint8_t* pass_sv = NULL; size_t pass_svl = 0;     /* the signature that verified */
   for (long hx = 0; hx < pm.nh && !passed; hx++) {
     const uint32_t* sp = pm.spans + 4 * hx;
     if (!key_ieq(raw + sp[0], sp[1] - sp[0], (const uint8_t*)"DKIM-Signature", 14)) continue;
     uint32_t this_ix = sig_ix++;
     const uint8_t* sv = raw + sp[2]; size_t svl = sp[3] - sp[2];
     if (value_has_non_ascii(sv, svl)) { unsupported = ZKE_D_U_SIG_NON_ASCII; out->sig_index = this_ix; continue; }
-    int v = validate_header(sv, svl, &tl);
+    int v = validate_header(sv, svl, &tl, strict, now);
     if (v == ZKE_D_U_TOO_MANY_TAGS || v == ZKE_D_U_SIG_TOO_LONG) { unsupported = v; out->sig_index = this_ix; continue; }
     if (v) { last_err = (uint32_t)v; out->sig_index = this_ix; continue; }
     const tag_t* td = get_tag(&tl, sv, "d");
     if (!key_ieq(tl.tagbuf + td->val_off, td->val_len, dom, dom_len)) continue;
     out->sig_index = this_ix;
     int algo_uns = 0;
-    int c = canon_for_sig(&pm, sv, svl, &tl, &cn, &algo_uns);
+    int c = canon_for_sig(&pm, sv, svl, &tl, &cn, &algo_uns, strict);
     if (c == ZKE_D_BAD_CANON || c == ZKE_D_BAD_ALGO) { last_err = (uint32_t)c; continue; }
     /* a= and the key type must name the same scheme; cfdkim's behaviour for a mixed pair is not restated */
     if ((algo_uns != 0) != ed_key) { unsupported = ZKE_D_U_ALGO_ED25519; continue; }
@@ -1391,7 +1454,7 @@ static void verify_one(const zke_batch* in, uint32_t i, zke_result* out, zke_deb
       int ok = sl == 64 && zko_ed25519_verify_strict(key, out->header_hash, 32, sigbuf);
       free(sigbuf);
       if (!ok) { last_err = ZKE_D_SIG_MISMATCH; continue; }
-      passed = 1;
+      passed = 1; pass_sv = sv; pass_svl = svl;
       continue;
     }
     if (!(mod[mod_len - 1] & 1) && !(mod_len == 1 && mod[0] == 0)) { free(sigbuf); unsupported = ZKE_D_U_EVEN_MODULUS; continue; }
@@ -1402,7 +1465,7 @@ static void verify_one(const zke_batch* in, uint32_t i, zke_result* out, zke_deb
     if (dbg && dbg->em) dbg_copy(dbg->em, dbg->em_stride, i, em, mod_len);
     free(sigbuf);
     if (!ok) { last_err = ZKE_D_SIG_MISMATCH; continue; }
-    passed = 1;
+    passed = 1; pass_sv = sv; pass_svl = svl;
   }
   if (!passed) {                                                       /* circuits.rs:13 */
     if (unsupported) { out->status = ZKE_UNSUPPORTED; out->detail = unsupported; }
@@ -1421,41 +1484,50 @@ static void verify_one(const zke_batch* in, uint32_t i, zke_result* out, zke_deb
     const uint32_t* sp = pm.spans + 4 * hx;
     if (key_ieq(raw + sp[0], sp[1] - sp[0], (const uint8_t*)"DKIM-Signature", 14)) { sv = raw + sp[2]; svl = sp[3] - sp[2]; break; }
   }
+  /* STRICTNESS SITE canon_takes_verified_signature.  Default: the FIRST DKIM-Signature header, whatever its d=.
+   * ZKE_STRICT_CANON_VERIFIED: the signature verify_dkim accepted. */
+  if (strict & ZKE_STRICT_CANON_VERIFIED) { sv = pass_sv; svl = pass_svl; }
   if (!sv) { out->status = ZKE_CANON_FAIL; out->detail = ZKE_D_NO_SIGNATURE; return; }
   if (value_has_non_ascii(sv, svl)) { out->status = ZKE_UNSUPPORTED; out->detail = ZKE_D_U_SIG_NON_ASCII; return; }
-  int v = validate_header(sv, svl, &tl);
+  int v = validate_header(sv, svl, &tl, strict, now);
   if (v == ZKE_D_U_TOO_MANY_TAGS || v == ZKE_D_U_SIG_TOO_LONG) { out->status = ZKE_UNSUPPORTED; out->detail = (uint32_t)v; return; }
   if (v) { out->status = ZKE_CANON_FAIL; out->detail = (uint32_t)v; return; }
-  v = canon_for_sig(&pm, sv, svl, &tl, &cn, NULL);
+  v = canon_for_sig(&pm, sv, svl, &tl, &cn, NULL, strict);
   if (v) { out->status = ZKE_CANON_FAIL; out->detail = (uint32_t)v; return; }
+  /* STRICTNESS SITE canon_ignores_l.  Default: the canonical body is truncated to l=, as on the verify path.
+   * ZKE_STRICT_CANON_IGNORES_L: canonicalize_signed_email returns the whole canonical body. */
+  if (strict & ZKE_STRICT_CANON_IGNORES_L) cn.cbody_len = cn.cbody_full;
   zko_remove_qp_soft_breaks(cn.cbody, cn.cbody_len, sc->clean);       /* circuits.rs:37 */
   if (dbg) dbg_copy(dbg->clean_body, dbg->clean_body_stride, i, sc->clean, cn.cbody_len);
   int decode_fail = 0;
   int d = process_parts(in, i, in->header_part_ids, in->n_header_parts, 0, cn.preimage, cn.preimage_len, out, &decode_fail);
-  if (decode_fail) { out->status = ZKE_DFA_DECODE_FAIL; return; }
+  if (decode_fail) { out->status = ZKE_DFA_DECODE_FAIL; out->detail = (uint32_t)decode_fail; return; }
   if (d) { out->status = (d == ZKE_D_U_CAPTURE_FFFD) ? ZKE_UNSUPPORTED : ZKE_HEADER_REGEX_FAIL; out->detail = (uint32_t)d; return; }
   d = process_parts(in, i, in->body_part_ids, in->n_body_parts, in->n_header_parts, sc->clean, cn.cbody_len, out, &decode_fail);
-  if (decode_fail) { out->status = ZKE_DFA_DECODE_FAIL; return; }
+  if (decode_fail) { out->status = ZKE_DFA_DECODE_FAIL; out->detail = (uint32_t)decode_fail; return; }
   if (d) { out->status = (d == ZKE_D_U_CAPTURE_FFFD) ? ZKE_UNSUPPORTED : ZKE_BODY_REGEX_FAIL; out->detail = (uint32_t)d; return; }
 }
 
-typedef struct { const zke_batch* in; zke_result* out; zke_debug_out* dbg; uint32_t lo, hi; } job_t;
+typedef struct { const zke_batch* in; zke_result* out; zke_debug_out* dbg; uint32_t lo, hi; uint32_t strict; uint64_t now; } job_t;
 static void* worker(void* a) {
   job_t* j = (job_t*)a;
   scratch_t sc; memset(&sc, 0, sizeof sc);
-  for (uint32_t i = j->lo; i < j->hi; i++) verify_one(j->in, i, &j->out[i], j->dbg, &sc);
+  for (uint32_t i = j->lo; i < j->hi; i++) verify_one(j->in, i, &j->out[i], j->dbg, &sc, j->strict, j->now);
   free(sc.spans); free(sc.tagbuf); free(sc.preimage); free(sc.cbody); free(sc.clean);
   return NULL;
 }
 int zko_verify_batch(const zke_batch* in, zke_result* out, zke_debug_out* dbg, int threads) {
+  return zko_verify_batch_strict(in, out, dbg, threads, 0, 0);
+}
+int zko_verify_batch_strict(const zke_batch* in, zke_result* out, zke_debug_out* dbg, int threads, uint32_t strict, uint64_t now) {
   if (!in || !out) return ZKE_E_ARG;
   if (threads < 1) threads = 1;
   if ((uint32_t)threads > in->n) threads = in->n ? (int)in->n : 1;
-  if (threads == 1) { job_t j = {in, out, dbg, 0, in->n}; worker(&j); return 0; }
+  if (threads == 1) { job_t j = {in, out, dbg, 0, in->n, strict, now}; worker(&j); return 0; }
   pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * threads);
   job_t* jobs = (job_t*)malloc(sizeof(job_t) * threads);
   for (int t = 0; t < threads; t++) {
-    jobs[t].in = in; jobs[t].out = out; jobs[t].dbg = dbg;
+    jobs[t].in = in; jobs[t].out = out; jobs[t].dbg = dbg; jobs[t].strict = strict; jobs[t].now = now;
     jobs[t].lo = (uint32_t)((uint64_t)in->n * t / threads);
     jobs[t].hi = (uint32_t)((uint64_t)in->n * (t + 1) / threads);
     pthread_create(&th[t], NULL, worker, &jobs[t]);

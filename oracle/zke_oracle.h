@@ -10,8 +10,9 @@
  * sha2 0.10.9, rsa 0.9.6, regex-automata 0.4.9, mailparse 0.15.0; Cargo.lock).  This
  * restatement follows their published algorithms (FIPS 180-4, RFC 8017, RFC 6376,
  * RFC 2045, regex-automata's dense-DFA wire format) and the reference's own call sites;
- * it is pinned by NIST / RFC known-answer vectors and by the independent Python
- * generator in tools/gen_golden.py (hashlib, int pow, openssl, `re`).
+ * it is pinned by NIST / RFC known-answer vectors, the RFC 8463 Appendix A message, two dense
+ * DFAs regex-automata itself serialised, and the independent Python signer in tests/synth.py
+ * (hashlib, int pow, openssl, `re`).
  */
 #ifndef ZKE_ORACLE_H
 #define ZKE_ORACLE_H
@@ -63,6 +64,7 @@ void zko_remove_qp_soft_breaks(const uint8_t* body, size_t len, uint8_t* out);
 /* regex-automata 0.4.9 dense DFA (little-endian wire format). */
 int zko_dfa_register(const uint8_t* fwd, size_t fwd_len, const uint8_t* bwd, size_t bwd_len,
                      uint32_t* out_id);
+long zko_dfa_status(uint32_t id);   /* 0, or the ZKE_D_DFA_* section at which the pair does not deserialise; -1: no such id */
 void zko_dfa_reset(void);
 /* find_iter over `hay`: writes up to max_spans (start,end) pairs; returns the count, or -1 on quit,
  * -2 if the id is unknown / blob invalid */
@@ -71,6 +73,9 @@ long zko_regex_find_iter(uint32_t id, const uint8_t* hay, size_t len, uint32_t* 
 /* verify_email / verify_email_with_regex over a batch (core/src/circuits.rs:9-68), one
  * email at a time exactly as the reference orders the work.  threads<=1: serial. */
 int zko_verify_batch(const zke_batch* in, zke_result* out, zke_debug_out* dbg, int threads);
+/* ... with the strictness flags of zke_options as a ZKE_STRICT_* mask (each switches the site of the same name here and
+ * in csrc/parse.hip.h) and the time x= is compared with */
+int zko_verify_batch_strict(const zke_batch* in, zke_result* out, zke_debug_out* dbg, int threads, uint32_t strict, uint64_t now);
 
 #ifdef __cplusplus
 }

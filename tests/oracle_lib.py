@@ -55,6 +55,10 @@ class Oracle:
         lib.zko_regex_find_iter.restype = C.c_long
         lib.zko_verify_batch.argtypes = [C.POINTER(A.zke_batch), vp, C.POINTER(A.zke_debug_out), C.c_int]
         lib.zko_verify_batch.restype = C.c_int
+        lib.zko_verify_batch_strict.argtypes = [C.POINTER(A.zke_batch), vp, C.POINTER(A.zke_debug_out), C.c_int, C.c_uint32, C.c_uint64]
+        lib.zko_verify_batch_strict.restype = C.c_int
+        lib.zko_dfa_status.argtypes = [C.c_uint32]
+        lib.zko_dfa_status.restype = C.c_long
         self._dfa_cache = {}
 
     @staticmethod
@@ -162,10 +166,14 @@ class Oracle:
             return int(n), []
         return int(n), [(sp[2 * i], sp[2 * i + 1]) for i in range(min(n, max_spans))]
 
-    def verify_batch(self, batch: "A.PackedBatch", debug=None, threads: int = 1) -> np.ndarray:
+    def dfa_status(self, dfa_id: int) -> int:
+        return int(self.lib.zko_dfa_status(dfa_id))
+
+    def verify_batch(self, batch: "A.PackedBatch", debug=None, threads: int = 1, now: int = 0, **strict) -> np.ndarray:
+        """`strict`: zke_options' strictness flags by name (A.STRICT_FLAGS), `now`: the clock x= is compared with."""
         out = np.zeros(max(batch.n, 1), dtype=A.RESULT_DTYPE)
-        rc = self.lib.zko_verify_batch(C.byref(batch.c), out.ctypes.data, C.byref(debug.c) if debug is not None else None,
-                                       threads)
+        rc = self.lib.zko_verify_batch_strict(C.byref(batch.c), out.ctypes.data, C.byref(debug.c) if debug is not None else None,
+                                              threads, A.strict_mask(**strict), now)
         assert rc == 0
         return out[:batch.n]
 

@@ -38,7 +38,8 @@ def test_struct_layouts_match_header():
     for name, off in (("status", 0), ("from_domain_hash", 32), ("public_key_hash", 64), ("body_hash", 96),
                       ("header_hash", 128), ("regex_part", 160), ("rsa_bits", 176)):
         assert getattr(A.zke_result, name).offset == off == A.RESULT_DTYPE.fields[name][1]
-    assert C.sizeof(A.zke_options) == 32
+    assert C.sizeof(A.zke_options) == 104 and C.sizeof(A.zke_timings) == 32
+    assert A.zke_options.now_unix.offset == 64 and A.zke_options.enforce_expiry_x.offset == 36
     # status / detail constants agree with the header
     src = open(os.path.join(ROOT, "include", "zkemail_amd.h")).read()
     for m in re.finditer(r"\b(ZKE_(?:D_)?[A-Z0-9_]+)\s*=\s*(\d+)", src):
@@ -93,4 +94,8 @@ def test_null_arguments_are_refused_not_dereferenced():
     assert lib.zke_rsa_modexp_batch(None, None, None, None, 256, 0, None, None) == E_ARG
     assert lib.zke_ed25519_verify_batch(None, None, None, 32, None, 0, None) == E_ARG
     lib.zke_engine_destroy(None)          # a no-op, as free(NULL)
-    assert lib.zke_last_error(None) == b"null engine"
+    assert lib.zke_verify_batch_async(None, C.byref(b), out.ctypes.data, C.byref(C.c_uint64())) == E_ARG
+    assert lib.zke_batch_wait(None, 0) == E_ARG
+    assert lib.zke_dfa_status(None, 0, C.byref(u)) == E_ARG and lib.zke_dfa_unregister(None, 0) == E_ARG
+    assert isinstance(lib.zke_last_error(None), bytes)        # the calling thread's last failure message, "" if none
+    assert lib.zke_abi_version() == 3

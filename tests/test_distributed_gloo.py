@@ -33,6 +33,12 @@ assert allrec.tobytes() == full.tobytes(), "gathered records differ from the sin
 wit = D.gather_witnesses(local, [bounds[r + 1] - bounds[r] for r in range(world)])
 assert wit.tobytes() == D.witness_of(full).tobytes(), "gathered witnesses differ from the single-process batch"
 assert (wit["status"] == full["status"]).all() and (wit["public_key_hash"] == full["public_key_hash"]).all()
+# the product-level entry: ONE batch in, sharded by bytes, witnesses of the whole batch out in batch order (the oracle stands
+# in for the GPU engine on this CPU tier; the sharding, padding and gathering code is the one bench.py --scaling strong runs)
+sv = D.ShardedVerifier(orc, rank=rank, world=world)
+assert sv.load(wl.emails) == (lo, hi) and sv.bounds == bounds
+w2 = sv.verify()
+assert w2.tobytes() == D.witness_of(full).tobytes(), "ShardedVerifier: witnesses differ from the single-process batch"
 my_bytes = sum(sizes[lo:hi])
 tot = torch.tensor([my_bytes], dtype=torch.int64)
 dist.all_reduce(tot)

@@ -1,0 +1,151 @@
+"""-m gpu: the host-memory entry point as a drop-in caller uses it (core/src/circuits.rs:9 takes a RAM-resident &Email) — the
+asynchronous form through several submission slots, re-entrancy from many host threads on ONE engine (SURVEY §8(b) Threading:
+the reference's functions are re-entrant), slot timings, and the error path's slot hygiene."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+from zkemail_rs_amd import _abi as A
+
+import cases
+import synth
+from test_gpu_verify import assert_records_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _batches(count, n=96, seed0=300):
+    """`count` different batches (ragged bodies, a few invalid e-mails) and the oracle-independent expectation per e-mail."""
+    out = []
+    for k in range(count):
+        wl = synth.make_workload("host", n + 7 * k, 3000, rsa_bits=2048, n_keys=4, seed=seed0 + k, ragged=True, invalid_frac=0.1)
+        out.append((A.PackedBatch(wl.emails), wl))
+    return out
+
+
+def test_async_host_entry_through_slots(oracle):
+    """zke_verify_batch_async: 5 slots, 23 batches of 6 different shapes submitted back to back (each waits only when its slot
+    comes round again — a slot whose batch was never waited for delivers it before it is reused), out of order waits, double
+    waits; every record equal to the oracle's and to the synchronous entry's."""
+    import zkemail_rs_amd as z
+    eng = z.Engine(slots=5, host_threads=4)
+    try:
+        bs = _batches(6)
+        exp = [oracle.verify_batch(p, threads=4) for p, _ in bs]
+        eng.reserve(max(p.n for p, _ in bs), max(int(p.raw_off[-1]) for p, _ in bs), 5, 0)
+        eng.reserve_host(max(p.n for p, _ in bs), max(int(p.raw_off[-1] + p.domain_off[-1] + p.key_off[-1]) for p, _ in bs))
+        pending = []
+        for i in range(23):
+            p, wl = bs[i % len(bs)]
+            t, out = eng.verify_batch_async(p)
+            pending.append((t, out, i % len(bs)))
+        # the first 18 were retired by their slots' later batches: their records are there without a wait
+        for t, out, k in pending[:18]:
+            assert_records_equal(out, exp[k], None, f"retired by reuse (batch shape {k})")
+        for t, out, k in reversed(pending):         # waits in reverse order, then once more
+            eng.wait(t)
+            assert_records_equal(out, exp[k], None, f"async batch shape {k}")
+        for t, out, k in pending:
+            eng.wait(t)
+        # the synchronous wrapper and the single-e-mail entry share the path
+        for (p, wl), e in zip(bs[:2], exp):
+            assert_records_equal(eng.verify_batch(p), e, None, "sync wrapper")
+        n_ok = sum(int((e["status"] == 0).sum()) for e in exp)
+        assert n_ok == sum(sum(1 for it in wl.inter if it["corrupt"] is None) for _, wl in bs)
+        # an empty batch is a no-op with a ticket that is already done
+        t, out = eng.verify_batch_async(A.PackedBatch([]))
+        eng.wait(t)
+        with pytest.raises(z.EngineError):
+            eng.wait((10 ** 9 << 6) | 1)
+    finally:
+        eng.close()
+
+
+def test_four_threads_one_engine_records_identical_to_serial(oracle):
+    """4 host threads x 50 batches on one engine with 3 slots (so threads share slots), host and device entry mixed: every
+    record identical to a serial run."""
+    import torch
+    import bench
+    import zkemail_rs_amd as z
+    eng = z.Engine(slots=3, host_threads=2)
+    try:
+        bs = _batches(4, n=64, seed0=400)
+        serial = [eng.verify_batch(p).copy() for p, _ in bs]
+        for (p, _), s in zip(bs, serial):
+            assert_records_equal(s, oracle.verify_batch(p, threads=4), None, "serial run")
+        dev = torch.device("cuda", 0)
+        dbs = [bench.device_batch(torch, p, dev) for p, _ in bs]
+        errors = []
+
+        def worker(tid):
+            try:
+                outs_dev = [torch.zeros(p.n * 192, dtype=torch.uint8, device=dev) for p, _ in bs]
+                for it in range(50):
+                    k = (tid + it) % len(bs)
+                    p = bs[k][0]
+                    if it % 3 == 2:                     # the device-resident entry from the same thread
+                        cb, keep, totals = dbs[k]
+                        eng.verify_batch_device(cb, totals[0], totals[1], totals[2], outs_dev[k].data_ptr(), 0)
+                        eng.sync()
+                        got = outs_dev[k].cpu().numpy().view(A.RESULT_DTYPE)
+                    elif it % 3 == 1:
+                        t, got = eng.verify_batch_async(p)
+                        eng.wait(t)
+                    else:
+                        got = eng.verify_batch(p)
+                    for f in A.RESULT_DTYPE.names:
+                        if f != "reserved" and not (np.asarray(got[f]) == np.asarray(serial[k][f])).all():
+                            raise AssertionError(f"thread {tid} iteration {it}: field {f} differs from the serial run")
+            except Exception as ex:          # noqa: BLE001
+                errors.append(repr(ex))
+
+        ths = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join(timeout=300)
+        assert not errors, errors[:3]
+        assert not any(t.is_alive() for t in ths)
+    finally:
+        eng.close()
+
+
+def test_slot_timings_and_names(oracle):
+    """zke_timings names the three launches; a slot that has not run a timed batch reports zeros (not another slot's figures)."""
+    import zkemail_rs_amd as z
+    eng = z.Engine(slots=3)
+    try:
+        (p, wl), = _batches(1, n=128, seed0=500)
+        eng.set_timing(True)
+        eng.verify_batch(p)                                  # slot 0
+        t0 = eng.slot_timings(0)
+        assert t0["front_end_us"] > 0 and t0["hash_modexp_us"] > 0 and t0["ed_verdict_us"] > 0 and t0["h2d_us"] > 0 and t0["d2h_us"] > 0
+        assert t0["regex_prep_us"] == 0 and t0["dfa_us"] == 0
+        assert abs(t0["total_us"] - (t0["front_end_us"] + t0["hash_modexp_us"] + t0["ed_verdict_us"])) < 1.0
+        t2 = eng.slot_timings(2)
+        assert all(v == 0 for v in t2.values()), t2
+        assert eng.timings() == t0                            # the slot used most recently
+        with pytest.raises(z.EngineError):
+            eng.slot_timings(7)
+    finally:
+        eng.close()
+
+
+def test_single_email_entry_and_larger_than_reserved(oracle):
+    """zke_verify_email through the pinned path (a batch of one), then a batch larger than anything reserved (the staging and
+    the workspace grow), then small again."""
+    import zkemail_rs_amd as z
+    eng = z.Engine()
+    try:
+        c = [x for x in cases.build_cases() if x.status == A.ZKE_OK][:5]
+        for x in c:
+            out = eng.verify_email(x.email)
+            w = cases.expected_witness(x)
+            assert (out.from_domain_hash, out.public_key_hash) == w
+        (small, _), (big, _) = _batches(1, n=8, seed0=600)[0], _batches(1, n=700, seed0=601)[0]
+        for p in (small, big, small):
+            assert_records_equal(eng.verify_batch(p), oracle.verify_batch(p, threads=4), None, f"n={p.n}")
+    finally:
+        eng.close()

@@ -211,8 +211,8 @@ def test_mixed_key_types_one_batch(engine, oracle):
 
 
 def test_lane_dfa_kernel_variant_parity(tmp_path):
-    """The lane-per-e-mail DFA kernel (ZKE_DFA_WAVE=0; the default is the wave-per-e-mail one) must produce the same records
-    as the oracle; run in a subprocess because the choice is made at engine creation."""
+    """The lane-per-e-mail DFA kernel (zke_options.dfa_mapping = 1; small batches take the wave-per-e-mail one) must produce
+    the same records as the oracle; run in a subprocess so that a fault cannot take the test session with it."""
     import os, subprocess, sys, textwrap
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = textwrap.dedent(f"""
@@ -221,20 +221,20 @@ def test_lane_dfa_kernel_variant_parity(tmp_path):
         import oracle_lib, cases, test_gpu_verify as t, test_gpu_regex as tr
         import zkemail_rs_amd as z
         import synth
-        eng, orc = z.Engine(), oracle_lib.load()
+        eng, orc = z.Engine(dfa_mapping=1), oracle_lib.load()
         tr.test_first_signature_canonicalisation_parity(eng, orc)
         tr.test_regex_workload_parity(eng, orc, dict(n=96, body_len=4096, rsa_bits=4096, n_keys=8, n_header_parts=2,
                                                     n_body_parts=2, qp_frac=0.05, fail_frac=0.3, seed=5))
         tr.test_long_haystacks_chunk_map_parity(eng, orc)
         print("lane dfa ok")
     """)
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ZKE_DFA_WAVE="0"), capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "lane dfa ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_rsa_quad_kernel_variant_parity():
     """The four- / eight-lanes-per-signature RSA kernel (csrc/rsa_quad.hip.h) is chosen for batches of >= 2 048 e-mails; forced on
-    (ZKE_RSA_QUAD=1) it must give the oracle's records and EM blocks on the corpus (all key sizes, exponents, bad
+    (zke_options.rsa_lane_groups = 2) it must give the oracle's records and EM blocks on the corpus (all key sizes, exponents, bad
     signatures), the fuzz set, ragged / invalid / rsa-sha1 / mixed-key workloads and several signature rounds."""
     import os, subprocess, sys, textwrap
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -243,7 +243,7 @@ def test_rsa_quad_kernel_variant_parity():
         sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r})
         import oracle_lib, cases, test_gpu_verify as t
         import zkemail_rs_amd as z
-        eng, orc = z.Engine(), oracle_lib.load()
+        eng, orc = z.Engine(rsa_lane_groups=2), oracle_lib.load()
         t.test_case_corpus_parity(eng, orc)
         for seed in (99, 7, 12):
             t.test_mutation_fuzz_parity(eng, orc, seed)
@@ -257,7 +257,7 @@ def test_rsa_quad_kernel_variant_parity():
         t.test_rsa_routing_through_the_key_cache(eng, orc)
         print("rsa quad ok")
     """)
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ZKE_RSA_QUAD="1"), capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "rsa quad ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
@@ -268,7 +268,7 @@ def test_rsa_routing_through_the_key_cache(engine, oracle):
     (RSA-3072 / 4096) where that kernel is part of the launch — records and EM blocks identical both times and to the oracle.
     Signatures rsa 0.9.6 rejects before the arithmetic (s >= n, wrong length) are rejected by either routine."""
     import subprocess, tempfile
-    forced = os.environ.get("ZKE_RSA_QUAD") == "1"          # else the lane-group kernels join only large batches: parity only
+    forced = engine.options.rsa_lane_groups == 2            # else the lane-group kernels join only large batches: parity only
     fresh = []
     with tempfile.TemporaryDirectory() as td:
         for bits in (1024, 2048, 3072, 4096):
@@ -335,7 +335,7 @@ def test_signature_rounds(engine, oracle):
     """cfdkim tries an e-mail's same-domain signatures one after the other (behind core/src/email.rs:31-33).  The first
     is tried in the batch's launches, later ones by the e-mail's own wave inside the verdict launch — the same for the
     host and the device entry point: 1, 2, 3, 5 and 12 failing signatures in front of the good one verify with the
-    oracle's sig_index; the default cap is 16 candidates (options.reserved[0]): 20 failing ones are reported as
+    oracle's sig_index; the default cap is 16 candidates (zke_options.max_sig_rounds): 20 failing ones are reported as
     unsupported, never guessed, and pass on an engine that allows 32."""
     import zkemail_rs_amd as z
     ks = (1, 2, 3, 5, 12)

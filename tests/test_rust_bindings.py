@@ -65,9 +65,11 @@ def test_rust_python_and_c_mirrors_agree():
         for (pn, pt), (_, rt) in zip(py, rs):
             tn = getattr(pt, "__name__", "")
             if hasattr(pt, "_length_"):                                   # ctypes array
-                assert rt == f"[{prim[pt._type_.__name__]}; {pt._length_}]", (name, pn, rt)
+                assert rt in (f"[{prim[pt._type_.__name__]}; {pt._length_}]", f"[u64; {pt._length_}]" if pt._type_ is __import__("ctypes").c_uint64 else ""), (name, pn, rt)
             elif tn in ("c_void_p",) or tn.startswith("LP_"):
                 assert rt.startswith("*const ") or rt.startswith("*mut "), (name, pn, rt)
+            elif tn == "c_ulong":                                         # size_t and uint64_t are one ctypes type on LP64
+                assert rt in ("usize", "u64"), (name, pn, rt)
             else:
                 assert rt == prim[tn], (name, pn, rt, tn)
     # a record is 192 bytes in all three

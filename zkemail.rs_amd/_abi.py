@@ -52,6 +52,7 @@ D_BAD_LENGTH = 10
 D_BODY_HASH_MISMATCH = 11
 D_SIG_B64 = 12
 D_SIG_MISMATCH = 13
+D_SIG_EXPIRED = 14
 D_HDR_LEADING_SPACE = 20
 D_HDR_LONE_CR = 21
 D_SUBPART_LEADING_SPACE = 23
@@ -80,6 +81,9 @@ D_U_DOMAIN_FOLD = 66
 D_U_MIME_CTYPE = 67
 D_U_MIME_BOUNDARY = 68
 D_U_MIME_DEPTH = 69
+D_DFA_LABEL, D_DFA_ENDIAN_VERSION, D_DFA_FLAGS, D_DFA_TRANSITIONS, D_DFA_START_TABLE = 70, 71, 72, 73, 74
+D_DFA_MATCH_STATES, D_DFA_SPECIAL, D_DFA_ACCELS, D_DFA_QUITSET, D_DFA_UNREGISTERED = 75, 76, 77, 78, 79
+D_DFA_BWD_OFFSET = 10
 
 KEY_RSA, KEY_ED25519, KEY_OTHER = 0, 1, 2
 F_HDR_RELAXED, F_BODY_RELAXED, F_HAS_LENGTH, F_SHA1, F_ED25519 = 1, 2, 4, 8, 16
@@ -147,14 +151,34 @@ class zke_regex_part(C.Structure):
     ]
 
 
+STRICT_FLAGS = ("enforce_expiry_x", "canon_takes_verified_signature", "canon_ignores_l", "i_must_be_subdomain",
+                "b_removes_own_span_only")          # zke_options' strictness flags, in ZKE_STRICT_* bit order
+
+
 class zke_options(C.Structure):
-    _fields_ = [("device", C.c_int32), ("reserved", C.c_uint32 * 7)]
+    """ABI 0.3: named fields; a zero-filled struct is the default configuration (device 0)."""
+    _fields_ = [
+        ("device", C.c_int32), ("slots", C.c_uint32), ("max_sig_rounds", C.c_uint32), ("disable_key_cache", C.c_uint32),
+        ("host_threads", C.c_uint32), ("max_dfas", C.c_uint32),
+        ("rsa_lane_groups", C.c_uint32), ("dfa_mapping", C.c_uint32), ("replay_graphs", C.c_uint32),
+        ("enforce_expiry_x", C.c_uint32), ("canon_takes_verified_signature", C.c_uint32), ("canon_ignores_l", C.c_uint32),
+        ("i_must_be_subdomain", C.c_uint32), ("b_removes_own_span_only", C.c_uint32), ("reserved0", C.c_uint32),
+        ("now_unix", C.c_uint64), ("reserved", C.c_uint64 * 4),
+    ]
+
+
+assert C.sizeof(zke_options) == 104
+
+
+def strict_mask(**flags) -> int:
+    """ZKE_STRICT_* mask of the named strictness flags (what the oracle's zko_verify_batch_strict takes)."""
+    assert set(flags) <= set(STRICT_FLAGS), flags
+    return sum(1 << k for k, name in enumerate(STRICT_FLAGS) if flags.get(name))
 
 
 class zke_timings(C.Structure):
     _fields_ = [(k, C.c_float) for k in (
-        "parse_us", "canon_body_us", "sha_us", "rsa_us", "qp_us", "dfa_us", "finalize_us", "total_us",
-        "h2d_us", "d2h_us")]
+        "front_end_us", "hash_modexp_us", "ed_verdict_us", "regex_prep_us", "dfa_us", "total_us", "h2d_us", "d2h_us")]
 
 
 # ---- the reference's input structs (core/src/structs.rs) ------------------------------

@@ -42,7 +42,7 @@ __device__ __forceinline__ uint32_t trailing_crlf_pairs(LD load, uint32_t len, b
   return matched / 2;
 }
 
-struct CanonArgs { BatchDev b; uint32_t mode; };
+struct CanonArgs { BatchDev b; uint32_t mode; uint32_t strict; };
 
 // Canonicalise the body of e-mail i with the calling wave.  `flags`, `boff`, `blen` and the l= value are handed
 // over in registers: the wave-per-e-mail front end calls this right after it has chosen the candidate signature
@@ -51,7 +51,7 @@ struct CanonArgs { BatchDev b; uint32_t mode; };
 constexpr uint32_t CANON_LDS_TRASH = 3504, CANON_LDS_BYTES = 3504 + 64;
 static_assert(CANON_LDS_BYTES <= PARSE_STAGE_BYTES, "the front end lends its staging buffer to the canonicaliser");
 __device__ __forceinline__ void canon_body_wave(const BatchDev& B, uint32_t i, uint32_t mode, uint32_t flags, uint32_t boff,
-                                                uint32_t blen, uint64_t len_tag, uint8_t* lds) {
+                                                uint32_t blen, uint64_t len_tag, uint8_t* lds, bool ignore_l) {
   const int lane = lane_id();
   EmailMeta* M = B.meta + i;
   zke_result* R = B.results + i;
@@ -284,7 +284,8 @@ __device__ __forceinline__ void canon_body_wave(const BatchDev& B, uint32_t i, u
     full = o;
   }
   uint32_t hashed = full;
-  if (flags & ZKE_F_HAS_LENGTH) {
+  // STRICTNESS SITE canon_ignores_l (mode 1 only: ignore_l): canonicalize_signed_email returns the whole canonical body
+  if ((flags & ZKE_F_HAS_LENGTH) && !ignore_l) {
     if (len_tag < hashed) hashed = (uint32_t)len_tag;
   }
   if (lane == 0) {
@@ -298,7 +299,7 @@ __device__ __forceinline__ void canon_body_wave(const BatchDev& B, uint32_t i, u
   }
 }
 
-// stand-alone launch: the canonicalize_signed_email pass (mode 1), and mode 0 under ZKE_NO_FUSE_CANON=1
+// stand-alone launch: the canonicalize_signed_email pass (mode 1)
 __global__ __launch_bounds__(64) void canon_body_kernel(CanonArgs A) {
   const BatchDev& B = A.b;
   const uint32_t i = blockIdx.x;
@@ -307,7 +308,8 @@ __global__ __launch_bounds__(64) void canon_body_kernel(CanonArgs A) {
   if (M->state != ST_CAND) return;
   if (A.mode == 1 && M->reuse) return;
   __shared__ __attribute__((aligned(16))) uint8_t canon_lds[CANON_LDS_BYTES];
-  canon_body_wave(B, i, A.mode, M->flags, M->body_off, M->body_len, ((uint64_t)M->len_tag_hi << 32) | M->len_tag_lo, canon_lds);
+  canon_body_wave(B, i, A.mode, M->flags, M->body_off, M->body_len, ((uint64_t)M->len_tag_hi << 32) | M->len_tag_lo, canon_lds,
+                  A.mode == 1 && (A.strict & ZKE_STRICT_CANON_IGNORES_L));
 }
 
 // ---- verdict of one signature round, by the wave that ran the e-mail's RSA job -----------------------

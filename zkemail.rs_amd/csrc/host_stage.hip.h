@@ -1,0 +1,139 @@
+// host_stage.hip.h — the host side of the host-memory entry point (zke_verify_batch[_async]): pinned staging memory and the
+// worker threads that fill it.
+//
+// The drop-in caller holds `&[Email]` in ordinary (pageable) RAM (core/src/circuits.rs:9; built at
+// helpers/src/generator.rs:40-45).  A DMA engine reads pinned memory only, so every byte crosses the host's memory once
+// before it crosses PCIe: pageable -> the slot's pinned image (here, by `host_threads` threads: one thread copies ~10 GB/s,
+// a Gen5 x16 link moves ~55), then ONE hipMemcpyAsync of the whole image on the slot's stream.  Included by engine.hip.
+#pragma once
+
+#include <condition_variable>
+#include <functional>
+#include <thread>
+
+namespace {
+
+struct PinnedBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t need) {
+    if (need <= cap) return 0;
+    if (p) (void)hipHostFree(p);
+    p = nullptr; cap = 0;
+    const size_t want = std::max(need + need / 4, (size_t)4096);
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; return ZKE_E_NOMEM; }
+    cap = want;
+    return 0;
+  }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// A handful of threads that do nothing but memcpy.  Several callers may use the pool at once (each call waits for its own
+// pieces only); with one thread configured, or for small copies, the caller's thread does the work itself.
+class CopyPool {
+ public:
+  explicit CopyPool(unsigned workers) {
+    for (unsigned i = 0; i < workers; i++) threads_.emplace_back([this] { run(); });
+  }
+  ~CopyPool() {
+    { std::lock_guard<std::mutex> g(mu_); stop_ = true; }
+    cv_.notify_all();
+    for (auto& t : threads_) t.join();
+  }
+  // the pieces of one packing job; returns when all of them are done
+  struct Piece { void* dst; const void* src; size_t n; };
+  void copy(const Piece* pieces, size_t count) {
+    constexpr size_t CHUNK = 256 << 10;           // below this a hand-over costs more than the copy
+    std::vector<Piece> work;
+    for (size_t i = 0; i < count; i++) {
+      const Piece& p = pieces[i];
+      if (!p.n) continue;
+      if (threads_.empty() || p.n < 2 * CHUNK) { work.push_back(p); continue; }
+      const size_t parts = std::min<size_t>(threads_.size() + 1, (p.n + CHUNK - 1) / CHUNK);
+      const size_t step = ((p.n + parts - 1) / parts + 63) & ~(size_t)63;
+      for (size_t o = 0; o < p.n; o += step)
+        work.push_back(Piece{(uint8_t*)p.dst + o, (const uint8_t*)p.src + o, std::min(step, p.n - o)});
+    }
+    if (work.empty()) return;
+    size_t big = 0;
+    for (const Piece& p : work) big += p.n >= CHUNK;
+    if (threads_.empty() || big < 2) {            // nothing worth sharing
+      for (const Piece& p : work) memcpy(p.dst, p.src, p.n);
+      return;
+    }
+    Job job;
+    job.left = work.size();
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      for (const Piece& p : work) queue_.push_back(Task{p, &job});
+    }
+    cv_.notify_all();
+    // the caller works too: it takes tasks until the queue is empty, then waits for the stragglers
+    for (;;) {
+      Task t;
+      {
+        std::lock_guard<std::mutex> g(mu_);
+        if (queue_.empty()) break;
+        t = queue_.back(); queue_.pop_back();
+      }
+      do_task(t);
+    }
+    std::unique_lock<std::mutex> lk(job.mu);
+    job.cv.wait(lk, [&] { return job.left == 0; });
+  }
+
+ private:
+  struct Job { std::mutex mu; std::condition_variable cv; size_t left = 0; };
+  struct Task { Piece p; Job* job; };
+  void do_task(const Task& t) {
+    memcpy(t.p.dst, t.p.src, t.p.n);
+    std::lock_guard<std::mutex> g(t.job->mu);
+    if (--t.job->left == 0) t.job->cv.notify_all();
+  }
+  void run() {
+    for (;;) {
+      Task t;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return stop_ || !queue_.empty(); });
+        if (stop_ && queue_.empty()) return;
+        t = queue_.back(); queue_.pop_back();
+      }
+      do_task(t);
+    }
+  }
+  std::vector<std::thread> threads_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::vector<Task> queue_;
+  bool stop_ = false;
+};
+
+// Layout of one batch's packed input image: the same bytes in the slot's pinned buffer and in HBM.  Offsets are into
+// the image; blobs start 64-byte aligned and are followed by 64 bytes of slack (the kernels read 16 bytes at a time).
+struct ImageLayout {
+  size_t raw_off, dom_off, key_off, key_type, ext_null, cap_off, cap_str_off, raw, dom, key, cap_blob, total;
+};
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) & ~(a - 1); }
+inline ImageLayout image_layout(uint32_t n, size_t raw_total, size_t dom_total, size_t key_total, size_t n_cap_off, size_t n_cap_str,
+                                size_t cap_bytes) {
+  ImageLayout L{};
+  size_t o = 0;
+  auto put = [&](size_t bytes, size_t slack) { const size_t at = o; o = align_up(o + bytes + slack, 64); return at; };
+  L.raw_off = put((size_t)(n + 1) * 8, 0);
+  L.dom_off = put((size_t)(n + 1) * 8, 0);
+  L.key_off = put((size_t)(n + 1) * 8, 0);
+  L.key_type = put(n, 0);
+  L.ext_null = put(n, 0);
+  L.cap_off = put(n_cap_off * 4, 0);
+  L.cap_str_off = put(n_cap_str * 4, 0);
+  L.raw = put(raw_total, 64);
+  L.dom = put(dom_total, 64);
+  L.key = put(key_total, 64);
+  L.cap_blob = put(cap_bytes, 64);
+  L.total = o;
+  return L;
+}
+
+}  // namespace

@@ -67,7 +67,7 @@ struct EmailMeta {
 static_assert(sizeof(EmailMeta) % 8 == 0, "EmailMeta alignment");
 
 enum : uint32_t { ST_FINAL = 0, ST_CAND = 1, ST_PENDING = 2 };
-enum : int { TG_V = 0, TG_A, TG_B, TG_BH, TG_D, TG_H, TG_S, TG_I, TG_Q, TG_C, TG_L, TG_N };
+enum : int { TG_V = 0, TG_A, TG_B, TG_BH, TG_D, TG_H, TG_S, TG_I, TG_Q, TG_C, TG_L, TG_X, TG_N };
 
 // Batch view handed to the kernels (device pointers).
 struct BatchDev {
@@ -417,7 +417,7 @@ __device__ __forceinline__ uint32_t parse_tag_spec(ParseLds& L, const Str& v, Wi
     switch (c0) {
       case 'v': id = TG_V; break; case 'a': id = TG_A; break; case 'b': id = TG_B; break; case 'd': id = TG_D; break;
       case 'h': id = TG_H; break; case 's': id = TG_S; break; case 'i': id = TG_I; break; case 'q': id = TG_Q; break;
-      case 'c': id = TG_C; break; case 'l': id = TG_L; break; default: break;
+      case 'c': id = TG_C; break; case 'l': id = TG_L; break; case 'x': id = TG_X; break; default: break;
     }
   } else if (ne - ns == 2 && c0 == 'b' && at(v, w, ns + 1) == 'h') {
     id = TG_BH;
@@ -536,7 +536,7 @@ __device__ __forceinline__ uint32_t taglist_lanes(ParseLds& L, const Str& v, uin
     switch (c0) {
       case 'v': id = TG_V; break; case 'a': id = TG_A; break; case 'b': id = TG_B; break; case 'd': id = TG_D; break;
       case 'h': id = TG_H; break; case 's': id = TG_S; break; case 'i': id = TG_I; break; case 'q': id = TG_Q; break;
-      case 'c': id = TG_C; break; case 'l': id = TG_L; break; default: break;
+      case 'c': id = TG_C; break; case 'l': id = TG_L; break; case 'x': id = TG_X; break; default: break;
     }
   } else if (mine && nl == 2 && c0 == 'b' && c1 == 'h') {
     id = TG_BH;
@@ -583,8 +583,10 @@ __device__ __forceinline__ uint32_t taglist_lanes(ParseLds& L, const Str& v, uin
 
 // cfdkim validate_header over the header value v.  0 = valid, else ZKE_D_* (ZKE_D_U_SIG_NON_ASCII: a byte >= 0x80 —
 // from_utf8_lossy would rewrite it — is reported, never guessed)
+// `strict`: ZKE_STRICT_* (zke_options' strictness flags: the readings of cfdkim that could not be verified offline); `now`: the
+// time x= is compared with.
 template <bool FAST>
-__device__ __forceinline__ uint32_t validate_sig(ParseLds& L, const Str& v, uint32_t& present) {
+__device__ __forceinline__ uint32_t validate_sig(ParseLds& L, const Str& v, uint32_t& present, uint32_t strict, uint64_t now) {
   uint32_t err = FAST ? taglist_lanes(L, v, present) : TL_SERIAL;
   if (err == TL_SERIAL) err = taglist_serial(L, v, present);
   if (err) return err;
@@ -593,15 +595,31 @@ __device__ __forceinline__ uint32_t validate_sig(ParseLds& L, const Str& v, uint
   const uint32_t req = (1u << TG_V) | (1u << TG_A) | (1u << TG_B) | (1u << TG_BH) | (1u << TG_D) | (1u << TG_H) | (1u << TG_S);
   if ((present & req) != req) return ZKE_D_MISSING_TAG;
   if (!tagval_eq(L, TG_V, LIT("1"))) return ZKE_D_INCOMPATIBLE_VERSION;
-  if (present & (1u << TG_I)) {   // user.ends_with(signing_domain)
+  if (present & (1u << TG_I)) {
+    // STRICTNESS SITE i_must_be_subdomain (oracle: validate_header, same name).  Default: user.ends_with(signing_domain), a plain
+    // suffix test on the bytes.  ZKE_STRICT_I_SUBDOMAIN: the domain of i= (behind its last '@'; the whole value without one)
+    // equals d= or ends with "." d=, ASCII case folded (RFC 6376 §3.5 "same as or a subdomain of").
     const uint32_t il = tagf(L, TG_I, 3), dl = tagf(L, TG_D, 3), io = tagf(L, TG_I, 2), dofs = tagf(L, TG_D, 2);
-    if (il < dl) return ZKE_D_DOMAIN_MISMATCH;
+    const bool sub = (strict & ZKE_STRICT_I_SUBDOMAIN) != 0;
+    uint32_t dom_s = 0;                 // where the domain of i= starts (sub only)
+    if (sub) {
+      for (uint32_t o = 0; o < il; o += 64) {
+        const uint32_t l = o + lane_id();
+        const uint64_t m = __ballot(l < il && L.tagbuf[io + l] == '@');
+        if (m) dom_s = o + 64u - (uint32_t)__builtin_clzll(m);
+      }
+    }
+    if (il - dom_s < dl) return ZKE_D_DOMAIN_MISMATCH;
     bool bad = false;
     for (uint32_t o = 0; o < dl; o += 64) {
       const uint32_t l = o + lane_id();
-      if (l < dl) bad |= L.tagbuf[io + il - dl + l] != L.tagbuf[dofs + l];
+      if (l < dl) {
+        const uint32_t a = L.tagbuf[io + il - dl + l], b = L.tagbuf[dofs + l];
+        bad |= sub ? lower(a) != lower(b) : a != b;
+      }
     }
     if (__ballot(bad)) return ZKE_D_DOMAIN_MISMATCH;
+    if (sub && il - dom_s > dl && uni(L.tagbuf[io + il - dl - 1]) != '.') return ZKE_D_DOMAIN_MISMATCH;
   }
   {   // h= must name "from" (split on ':', lower-cased)
     const uint32_t ho = tagf(L, TG_H, 2), hl = tagf(L, TG_H, 3);
@@ -618,6 +636,28 @@ __device__ __forceinline__ uint32_t validate_sig(ParseLds& L, const Str& v, uint
     if (!__ballot(found)) return ZKE_D_FROM_NOT_SIGNED;
   }
   if ((present & (1u << TG_Q)) && !tagval_eq(L, TG_Q, LIT("dns/txt"))) return ZKE_D_BAD_QUERY_METHOD;
+  if ((strict & ZKE_STRICT_EXPIRY_X) && (present & (1u << TG_X))) {
+    // STRICTNESS SITE enforce_expiry_x (oracle: validate_header, same name).  Default: x= is ignored — a zkVM guest has no clock.
+    // ZKE_STRICT_EXPIRY_X: cloudflare/dkim's rule — x= parsed as i64 (str::parse: optional sign, digits, no overflow; anything
+    // else counts as 0), fifteen minutes of drift allowed, expired when now > x + 900.
+    const uint8_t* xs = L.tagbuf + tagf(L, TG_X, 2);
+    const uint32_t xn = tagf(L, TG_X, 3);
+    uint32_t k = 0;
+    bool neg = false, okx = xn > 0;
+    if (okx) { const uint32_t c = uni(xs[0]); if (c == '+' || c == '-') { neg = c == '-'; k = 1; okx = xn > 1; } }
+    uint64_t mag = 0;
+    const uint64_t lim = neg ? (1ull << 63) : (1ull << 63) - 1;
+    for (; okx && k < xn; k++) {
+      const uint32_t c = uni(xs[k]);
+      if (c < '0' || c > '9') { okx = false; break; }
+      const uint64_t d = c - '0';
+      if (mag > (lim - d) / 10) { okx = false; break; }
+      mag = mag * 10 + d;
+    }
+    const int64_t x = okx ? (neg ? (int64_t)(0 - mag) : (int64_t)mag) : 0;
+    const int64_t deadline = x > INT64_MAX - 900 ? INT64_MAX : x + 900;
+    if ((int64_t)now > deadline) return ZKE_D_SIG_EXPIRED;
+  }
   return 0;
 }
 
@@ -984,17 +1024,25 @@ namespace zke {
 // mode 0: verify_email_with_key scan (round r picks the r-th same-domain candidate)
 // mode 1: canonicalize_signed_email (first DKIM-Signature header, no domain filter; core/src/circuits.rs:34-35)
 struct ParseArgs {
-  BatchDev b; uint32_t round; uint32_t mode; uint32_t debug_stop;
-  uint32_t fuse_canon;              // canonicalise the body here (mode 0)
+  BatchDev b; uint32_t round; uint32_t mode;
+  uint32_t debug_stop;              // ZKE_DEV_KNOBS builds only (stage ablation for the profiles): 0 everywhere else
+  uint32_t strict;                  // ZKE_STRICT_*: zke_options' strictness flags
+  uint64_t now;                     // the time x= is compared with (ZKE_STRICT_EXPIRY_X)
   const KeyCacheEntry* cache;       // per-key Montgomery constants (nullptr: no cache, every signature takes the wave routine)
   uint32_t route_mask;              // bit 0 / 1: the four- / eight-lane RSA kernel is part of this batch's hash / modexp launch
   uint32_t* wave_count;             // job list of the one-signature-per-wave RSA routine: the e-mails not routed to a lane-group kernel
   uint32_t* wave_list;              // (nullptr: no list, the routine looks at every job).  Appended here, consumed by the next launch.
 };
 
+#ifdef ZKE_DEV_KNOBS
+#define ZKE_DEV_STOP(k) do { if (A.debug_stop == (k)) return; } while (0)
+#else
+#define ZKE_DEV_STOP(k) do { } while (0)
+#endif
+
 // canon.hip.h
 __device__ __forceinline__ void canon_body_wave(const BatchDev& B, uint32_t i, uint32_t mode, uint32_t flags, uint32_t boff,
-                                                uint32_t blen, uint64_t len_tag, uint8_t* lds);   // debug_stop: timing experiments only (0 = off)
+                                                uint32_t blen, uint64_t len_tag, uint8_t* lds, bool ignore_l);
 
 
 // The front end of e-mail i by the calling wave (L: the wave's LDS image).  parse_kernel runs it for every e-mail of a
@@ -1033,7 +1081,7 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
     __builtin_amdgcn_wave_barrier();
     raw.lds = L.stage; raw.lds_len = want;
   }
-  if (A.debug_stop == 1) return;
+  ZKE_DEV_STOP(1);
   const Str dom = mkstr(B.dom + B.dom_off[i], (uint32_t)(B.dom_off[i + 1] - B.dom_off[i]));
   const Str key = mkstr(B.key + B.key_off[i], (uint32_t)(B.key_off[i + 1] - B.key_off[i]));
   uint8_t* regA = B.scratch + scratch_offset(r0 - B.raw_off[0], i);
@@ -1055,11 +1103,15 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     if (R->status != ZKE_OK) { finish(R->status, R->detail); return; }
     const EmailMeta* V = B.meta_verify + i;
-    if (V->first_sig_hdr == V->cand_hdr) {        // same signature: nothing to recompute
+    // STRICTNESS SITE canon_takes_verified_signature (oracle: verify_one, same name).  Default: canonicalize_signed_email takes
+    // the FIRST DKIM-Signature header, whatever its d=.  ZKE_STRICT_CANON_VERIFIED: the signature verify_dkim accepted.
+    if (V->first_sig_hdr == V->cand_hdr || (A.strict & ZKE_STRICT_CANON_VERIFIED)) {        // same signature: nothing to recompute
       if (lane == 0) {
         M->state = ST_CAND; M->reuse = 1; M->flags = V->flags; M->preimage_len = V->preimage_len;
         M->body_off = V->body_off; M->body_len = V->body_len; M->canon_full_len = V->canon_full_len;
-        M->hashed_len = V->hashed_len; M->body_src_is_raw = V->body_src_is_raw;
+        // STRICTNESS SITE canon_ignores_l (also canon_body_wave, mode 1): the whole canonical body instead of its first l= bytes
+        M->hashed_len = (A.strict & ZKE_STRICT_CANON_IGNORES_L) ? V->canon_full_len : V->hashed_len;
+        M->body_src_is_raw = V->body_src_is_raw;
         M->len_tag_lo = V->len_tag_lo; M->len_tag_hi = V->len_tag_hi;
       }
       return;
@@ -1086,9 +1138,9 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
     finish(perr == ZKE_D_U_TOO_MANY_HEADERS ? ZKE_UNSUPPORTED : ZKE_PARSE_FAIL, perr);
     return;
   }
-  if (A.debug_stop == 2) return;
+  ZKE_DEV_STOP(2);
   const uint32_t body_off = find_body(raw, hdr_end >= 2 ? hdr_end - 2 : 0);
-  if (A.debug_stop == 3) return;
+  ZKE_DEV_STOP(3);
   if (lane == 0) {
     if (A.mode == 0) { R->n_headers = nh; R->body_offset = body_off; }
     M->n_headers = nh; M->body_off = body_off; M->body_len = raw.len - body_off;
@@ -1150,7 +1202,7 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
     }
   }
 
-  if (A.debug_stop == 4) return;
+  ZKE_DEV_STOP(4);
   // ---- scan the DKIM-Signature headers in file order
   uint32_t sig_ix = 0, cand_count = 0, last_touched = 0, unsupported = 0;
   uint32_t err_all = 0;        // last non-candidate error anywhere
@@ -1171,8 +1223,8 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
     const Str v = substr(raw, vs, ve);
     auto note_err = [&](uint32_t e) { err_all = e; if (have_cand) err_after = e; last_touched = this_ix; };
     uint32_t present;
-    const uint32_t verr = validate_sig<FAST>(L, v, present);
-    if (A.debug_stop == 5) return;
+    const uint32_t verr = validate_sig<FAST>(L, v, present, A.strict, A.now);
+    ZKE_DEV_STOP(5);
     if (verr == ZKE_D_U_SIG_NON_ASCII || verr == ZKE_D_U_TOO_MANY_TAGS || verr == ZKE_D_U_SIG_TOO_LONG) {
       unsupported = verr; last_touched = this_ix;
       if (A.mode == 1) { finish(ZKE_UNSUPPORTED, verr); return; }
@@ -1270,7 +1322,9 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
         }
         return NONE;
       };
-      if (next_occurrence(0, b_rs) == NONE) {
+      // STRICTNESS SITE b_removes_own_span_only (oracle: build_preimage, same name).  Default: String::replace — every occurrence
+      // of the raw b= value goes.  ZKE_STRICT_B_OWN_SPAN: only the tag's own span is emptied.
+      if ((A.strict & ZKE_STRICT_B_OWN_SPAN) || next_occurrence(0, b_rs) == NONE) {
         sv.len = v.len - bl; sv.cut = b_rs; sv.skip = bl;
       } else {
         uint8_t* tmp = regA + (((size_t)raw.len + PRE_SLACK + 15) & ~(size_t)15);    // region B: raw.len + 16 bytes
@@ -1289,7 +1343,7 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
         sv = mkstr(tmp, tn);
       }
     }
-    if (A.debug_stop == 6) return;
+    ZKE_DEV_STOP(6);
     // ---- header-hash preimage (cfdkim hash::compute_headers_hash)
     Out out{regA, 0, capA, false};
     const bool hrel = (flags & ZKE_F_HDR_RELAXED) != 0;
@@ -1389,7 +1443,7 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
     else finish(ZKE_DKIM_NOT_PASS, err_all ? err_all : (round == 0 ? ZKE_D_NEUTRAL : M->cand_err));
     return;
   }
-  if (A.debug_stop == 7) return;        // ablation: full parse, nothing downstream
+  ZKE_DEV_STOP(7);        // ablation: full parse, nothing downstream
   if (lane == 0) {
     M->state = ST_CAND;
     // an Ed25519 candidate leaves the RSA job inactive; ed25519_email_kernel verifies it
@@ -1400,7 +1454,7 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
     if ((jf & RSA_F_ACTIVE) && !(jf & (RSA_F_QUAD | RSA_F_OCT)) && A.wave_list) A.wave_list[atomicAdd(A.wave_count, 1u)] = i;
   }
   // ---- body canonicalisation of the candidate (cfdkim hash::compute_body_hash), same wave, no launch boundary
-  if (A.fuse_canon) canon_body_wave(B, i, 0, cand_flags, body_off, raw.len - body_off, cand_len_tag, L.stage);   // parsing is over: the staged head is dead
+  canon_body_wave(B, i, 0, cand_flags, body_off, raw.len - body_off, cand_len_tag, L.stage, false);   // parsing is over: the staged head is dead
 }
 
 #ifndef ZKE_PARSE_PRIO

@@ -272,6 +272,7 @@ struct DfaArgs {
   PartRes* out;                     // [n * P]
   uint32_t lds_tables;              // 1: both tables fit the dynamic LDS allocation
   uint32_t idle;                    // dfa_wave_kernel: the forward automaton's idle state (host-chosen; ~0: none, plain serial search)
+  uint32_t decode_detail;           // re == nullptr: the ZKE_D_DFA_* section at which dense::DFA::from_bytes gives up (regex.rs:32-33)
 };
 
 // stage both automata of the part in the block's dynamic LDS (all threads of the block take part)
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(256) void dfa_kernel(DfaArgs A) {
   PartRes pr{PART_SKIPPED, 0, 0, 0};
   if (M->state == ST_CAND) {
     if (!valid) {
-      pr.code = PART_DECODE_FAIL;
+      pr.code = PART_DECODE_FAIL; pr.count = A.decode_detail;
     } else {
       const uint8_t* hay; uint32_t hlen;
       dfa_haystack(A, i, M, hay, hlen);
@@ -398,13 +399,14 @@ struct DfaMultiArgs {
   const RegexDev* re[DFA_MULTI_MAX];
   uint32_t lds_tables[DFA_MULTI_MAX];
   uint32_t idle[DFA_MULTI_MAX];
+  uint32_t detail[DFA_MULTI_MAX];
 };
 
 __global__ __launch_bounds__(256) void dfa_wave_kernel(DfaMultiArgs MA) {
   extern __shared__ __attribute__((aligned(16))) uint8_t dlds[];
   DfaArgs A = MA.common;
   A.part = MA.part0 + blockIdx.y;
-  A.re = MA.re[blockIdx.y]; A.lds_tables = MA.lds_tables[blockIdx.y]; A.idle = MA.idle[blockIdx.y];
+  A.re = MA.re[blockIdx.y]; A.lds_tables = MA.lds_tables[blockIdx.y]; A.idle = MA.idle[blockIdx.y]; A.decode_detail = MA.detail[blockIdx.y];
   A.is_body = A.part >= MA.n_header_parts ? 1u : 0u;
   const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -415,7 +417,7 @@ __global__ __launch_bounds__(256) void dfa_wave_kernel(DfaMultiArgs MA) {
   PartRes pr{PART_SKIPPED, 0, 0, 0};
   if (M->state == ST_CAND) {
     if (!valid) {
-      pr.code = PART_DECODE_FAIL;
+      pr.code = PART_DECODE_FAIL; pr.count = A.decode_detail;
     } else {
       const uint8_t* hay; uint32_t hlen;
       dfa_haystack(A, i, M, hay, hlen);
@@ -465,7 +467,7 @@ __global__ void regex_finalize_kernel(RegexFinArgs A) {
   for (uint32_t p = 0; p < P; p++) {
     const PartRes pr = A.parts[(size_t)i * P + p];
     R->regex_part = p; R->match_count = 0; R->match_start = 0; R->match_end = 0;
-    if (pr.code == PART_DECODE_FAIL) { R->status = ZKE_DFA_DECODE_FAIL; R->detail = 0; return; }   // regex.rs:32-33
+    if (pr.code == PART_DECODE_FAIL) { R->status = ZKE_DFA_DECODE_FAIL; R->detail = pr.count; return; }   // regex.rs:32-33; detail: the blob section
     R->match_count = pr.count; R->match_start = pr.start; R->match_end = pr.end;
     if (pr.code) {
       R->status = pr.code == ZKE_D_U_CAPTURE_FFFD ? ZKE_UNSUPPORTED

@@ -18,6 +18,8 @@ struct EdVerdictArgs {
   uint32_t* wave_count;      // the hash / modexp stage's job list is consumed: reset for the next batch
   KeyCacheEntry* cache;      // later signature rounds: per-key Montgomery constants
   uint8_t* em_out;           // parity intermediates (nullptr in production)
+  uint32_t strict;           // ZKE_STRICT_* and the x= clock, for the front end of later signature rounds
+  uint64_t now;
 };
 
 // SHA-256 / SHA-1 of one message by ONE LANE (later signature rounds only: two messages per e-mail, a rare path; the
@@ -73,7 +75,7 @@ __device__ __noinline__ void next_round(const EdVerdictArgs& A, uint32_t round, 
     const uint32_t e = base + (uint32_t)__builtin_ctzll(pend);
     const EmailMeta* M = B.meta + e;
     wave_publish();                                   // the verdict lane's EmailMeta / record stores
-    ParseArgs pa{B, round, 0, 0, 1, nullptr, 0, nullptr, nullptr};
+    ParseArgs pa{B, round, 0, 0, A.strict, A.now, nullptr, 0, nullptr, nullptr};
     parse_email<false>(pa, e, L);
     wave_publish();                                   // the front end's jobs, preimage and canonical body
     if (M->state != ST_CAND) continue;

@@ -56,6 +56,18 @@ def load_library(path: Optional[str] = None):
     lib.zke_dfa_register.restype = C.c_int
     lib.zke_verify_batch.argtypes = [vp, C.POINTER(A.zke_batch), vp, C.POINTER(A.zke_debug_out)]
     lib.zke_verify_batch.restype = C.c_int
+    lib.zke_verify_batch_async.argtypes = [vp, C.POINTER(A.zke_batch), vp, C.POINTER(C.c_uint64)]
+    lib.zke_verify_batch_async.restype = C.c_int
+    lib.zke_batch_wait.argtypes = [vp, C.c_uint64]
+    lib.zke_batch_wait.restype = C.c_int
+    lib.zke_dfa_status.argtypes = [vp, C.c_uint32, u32p]
+    lib.zke_dfa_status.restype = C.c_int
+    lib.zke_dfa_unregister.argtypes = [vp, C.c_uint32]
+    lib.zke_dfa_unregister.restype = C.c_int
+    lib.zke_process_init.argtypes = [C.c_uint32]
+    lib.zke_process_init.restype = C.c_int
+    lib.zke_abi_version.argtypes = []
+    lib.zke_abi_version.restype = C.c_uint32
     lib.zke_verify_batch_device.argtypes = [vp, C.POINTER(A.zke_batch), C.c_uint64, C.c_uint64, C.c_uint64, vp, vp]
     lib.zke_verify_batch_device.restype = C.c_int
     lib.zke_engine_sync.argtypes = [vp]
@@ -73,6 +85,8 @@ def load_library(path: Optional[str] = None):
     lib.zke_verify_email_with_regex.restype = C.c_int
     lib.zke_engine_reserve.argtypes = [vp, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32]
     lib.zke_engine_reserve.restype = C.c_int
+    lib.zke_engine_reserve_host.argtypes = [vp, C.c_uint32, C.c_uint64]
+    lib.zke_engine_reserve_host.restype = C.c_int
     lib.zke_get_slot_timings.argtypes = [vp, C.c_uint32, C.POINTER(A.zke_timings)]
     lib.zke_get_slot_timings.restype = C.c_int
     lib.zke_sha256_batch.argtypes = [vp, vp, vp, C.c_uint32, vp]
@@ -100,7 +114,8 @@ EXPORTED_SYMBOLS = [
     "zke_verify_batch_device", "zke_engine_sync", "zke_get_timings", "zke_set_timing", "zke_verify_email",
     "zke_sha256_batch", "zke_sha256_batch_device", "zke_rsa_modexp_batch", "zke_version", "zke_device_available",
     "zke_ed25519_verify_batch", "zke_engine_reserve", "zke_get_slot_timings", "zke_verify_email_with_regex",
-    "zke_abi_encode", "zke_engine_join",
+    "zke_abi_encode", "zke_engine_join", "zke_verify_batch_async", "zke_batch_wait", "zke_dfa_status", "zke_dfa_unregister",
+    "zke_process_init", "zke_abi_version", "zke_engine_reserve_host",
 ]
 
 
@@ -108,17 +123,27 @@ class Engine:
     """One engine per GPU (``zke_engine``): owns the device workspace, the stream and the
     registered DFA tables."""
 
-    def __init__(self, device: int = -1, max_sig_rounds: int = 0):
+    def __init__(self, device: int = -1, max_sig_rounds: int = 0, **options):
+        """`options`: any other field of ``zke_options`` by name — ``slots``, ``host_threads``, ``disable_key_cache``,
+        ``max_dfas``, the kernel variants ``rsa_lane_groups`` / ``dfa_mapping`` (0 by batch size, 1 / 2 forced),
+        ``replay_graphs``, the strictness flags of ``_abi.STRICT_FLAGS`` and ``now_unix``."""
         self.lib = load_library()
         if not self.lib.zke_device_available():
             raise EngineError("no HIP device visible; the engine has no CPU path")
         opt = A.zke_options()
         opt.device = device
-        opt.reserved[0] = max_sig_rounds          # same-domain signatures tried per e-mail (0 = the default, 16)
+        opt.max_sig_rounds = max_sig_rounds          # same-domain signatures tried per e-mail (0 = the default, 16)
+        names = {f[0] for f in A.zke_options._fields_} - {"reserved", "reserved0"}
+        for k, v in options.items():
+            if k not in names:
+                raise TypeError(f"zke_options has no field {k!r}")
+            setattr(opt, k, int(v))
+        self.options = opt
         h = C.c_void_p()
         rc = self.lib.zke_engine_create(C.byref(opt), C.byref(h))
         if rc != 0:
-            raise EngineError(f"zke_engine_create failed ({rc})")
+            msg = self.lib.zke_last_error(None)
+            raise EngineError(f"zke_engine_create failed ({rc}): {msg.decode() if msg else ''}")
         self.h = h
         self._dfa_cache: Dict[Tuple[bytes, bytes], int] = {}
 
@@ -151,7 +176,28 @@ class Engine:
         self._dfa_cache[key] = out.value
         return out.value
 
+    def dfa_status(self, dfa_id: int) -> int:
+        """0 when both blobs of the pair deserialise, else the ZKE_D_DFA_* section at which from_bytes gives up."""
+        d = C.c_uint32()
+        self._check(self.lib.zke_dfa_status(self.h, dfa_id, C.byref(d)), "zke_dfa_status")
+        return d.value
+
+    def dfa_unregister(self, dfa_id: int):
+        self._check(self.lib.zke_dfa_unregister(self.h, dfa_id), "zke_dfa_unregister")
+        self._dfa_cache = {k: v for k, v in self._dfa_cache.items() if v != dfa_id}
+
     # ---- batches
+    def verify_batch_async(self, batch: PackedBatch):
+        """zke_verify_batch_async: returns (ticket, records); the records are valid once ``wait(ticket)`` has returned.
+        The batch's buffers may be reused as soon as this returns."""
+        out = np.zeros(max(batch.n, 1), dtype=A.RESULT_DTYPE)
+        t = C.c_uint64()
+        self._check(self.lib.zke_verify_batch_async(self.h, C.byref(batch.c), out.ctypes.data, C.byref(t)), "zke_verify_batch_async")
+        return t.value, out[:batch.n]
+
+    def wait(self, ticket: int):
+        self._check(self.lib.zke_batch_wait(self.h, ticket), "zke_batch_wait")
+
     def verify_batch(self, batch: PackedBatch, debug: Optional[DebugBuffers] = None) -> np.ndarray:
         out = np.zeros(max(batch.n, 1), dtype=A.RESULT_DTYPE)
         self._check(self.lib.zke_verify_batch(self.h, C.byref(batch.c), out.ctypes.data,
@@ -167,6 +213,10 @@ class Engine:
         """Size `slots` submission slots for batches of up to max_n e-mails / max_raw_total raw bytes: nothing is
         allocated in the submit path afterwards; `slots` batches can be in flight (zke_engine_reserve)."""
         self._check(self.lib.zke_engine_reserve(self.h, max_n, max_raw_total, slots, max_regex_parts), "zke_engine_reserve")
+
+    def reserve_host(self, max_n: int, max_input_bytes: int):
+        """Size every slot's pinned staging for host-entry batches of up to max_n e-mails / max_input_bytes of inputs."""
+        self._check(self.lib.zke_engine_reserve_host(self.h, max_n, max_input_bytes), "zke_engine_reserve_host")
 
     def sync(self):
         self._check(self.lib.zke_engine_sync(self.h), "zke_engine_sync")
