@@ -57,6 +57,8 @@ def parse_args():
                     help="weak (default): every rank verifies its own batch of the configured size.  strong: ONE batch of the "
                          "configured size, sharded by cumulative bytes over the ranks (ShardedVerifier)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (host-memory entry) and single-e-mail latency legs")
+    ap.add_argument("--host-threads", type=int, default=0,
+                    help="threads that pack host-entry batches into pinned memory (zke_options.host_threads); default min(8, cores / 2)")
     ap.add_argument("--batch", type=int, default=0, help="override e-mails per step (default: the config's batch)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU baseline sample budget per leg")
     ap.add_argument("--no-cpu", action="store_true")
@@ -219,7 +221,7 @@ def main():
     # simply do not wait for each other, as a service with a queue of batches would run them.  The inputs are read-only
     # and shared.  zke_engine_reserve sizes every slot now: nothing is allocated once the steps start.
     host_cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    eng = z.Engine(device=local_rank, host_threads=max(1, min(8, host_cores // 2)))
+    eng = z.Engine(device=local_rank, host_threads=args.host_threads or max(1, min(8, host_cores // 2)))
     if regex_inputs is not None:
         packed = eng.pack_with_regex(regex_inputs)           # registers the DFAs of the part list
     else:

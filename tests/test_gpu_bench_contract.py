@@ -35,9 +35,22 @@ def test_bench_json_contract():
     pl = rf["per_launch"]
     for mode in ("in_flight", "alone"):
         assert abs(pl[mode]["achieved"] - rf["bytes_per_launch"] / (pl[mode]["launch_us"] * 1e-6) / 1e9) < 0.02 * pl[mode]["achieved"]
-    assert pl["alone"]["launch_us"] < pl["in_flight"]["launch_us"] and rf["traffic"] is None or rf["traffic"] >= rf["hashed_bytes"]
+    assert pl["alone"]["launch_us"] < pl["in_flight"]["launch_us"]
+    assert rf["traffic"] is None or rf["traffic"] >= rf["bytes_per_launch"]
+    # SURVEY §8(d)'s bytes for the SHA-256 body kernel: the canonical bodies once + 32 B per e-mail; the wider count beside it
+    assert rf["bytes_per_launch"] == 1024 * (4096 + 32) and rf["bytes_per_launch_all"] > rf["bytes_per_launch"]
+    ib = rf["issue_bound"]
+    if ib is not None:         # (from the committed PMC summary of the bench workload)
+        assert 0 < ib["frac_of_issue_bound"] <= 1.0 and abs(ib["issue_bound_us_per_step"] / (j["ms_per_step"] * 1e3) - ib["frac_of_issue_bound"]) < 1e-3
+    # the host-memory entry, H2D and D2H inside the clock, and the latency of one call
+    e2e = j["end_to_end"]
+    assert e2e["unit"] == "emails/s" and 1e5 < e2e["value"] <= j["value"] * 1.05
+    assert 0 < e2e["frac_of_pcie"] <= 1.05 and e2e["bytes_per_email_h2d"] > 4096
+    lat = j["single_email_latency_us"]
+    assert 20 < lat["gpu_p50"] <= lat["gpu_p90"] < 1e5 and lat["oracle_one_core_us"] > 10
+    assert lat["gpu_host_batch_us_by_n"]["1"] > 0
     cb = j["cpu_baseline"]
-    for k in ("value", "unit", "cores", "kind", "sample"):
+    for k in ("value", "unit", "cores", "kind", "sample", "cpu_model"):
         assert k in cb, k
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
 

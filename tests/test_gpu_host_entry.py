@@ -63,14 +63,23 @@ def test_async_host_entry_through_slots(oracle):
         eng.close()
 
 
-def test_four_threads_one_engine_records_identical_to_serial(oracle):
+def test_four_threads_one_engine_records_identical_to_serial():
     """4 host threads x 50 batches on one engine with 3 slots (so threads share slots), host and device entry mixed: every
-    record identical to a serial run."""
-    import torch
-    import bench
-    import zkemail_rs_amd as z
-    eng = z.Engine(slots=3, host_threads=2)
-    try:
+    record identical to a serial run.  (A subprocess: torch must initialise the GPU before the engine does in a process that
+    uses both.)"""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent(f"""
+        import sys, threading
+        sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r})
+        import numpy as np, torch
+        torch.zeros(1, device="cuda")
+        import bench, oracle_lib, zkemail_rs_amd as z
+        from zkemail_rs_amd import _abi as A
+        from test_gpu_host_entry import _batches
+        from test_gpu_verify import assert_records_equal
+        oracle = oracle_lib.load()
+        eng = z.Engine(slots=3, host_threads=2)
         bs = _batches(4, n=64, seed0=400)
         serial = [eng.verify_batch(p).copy() for p, _ in bs]
         for (p, _), s in zip(bs, serial):
@@ -87,6 +96,8 @@ def test_four_threads_one_engine_records_identical_to_serial(oracle):
                     p = bs[k][0]
                     if it % 3 == 2:                     # the device-resident entry from the same thread
                         cb, keep, totals = dbs[k]
+                        outs_dev[k].zero_()
+                        torch.cuda.synchronize()
                         eng.verify_batch_device(cb, totals[0], totals[1], totals[2], outs_dev[k].data_ptr(), 0)
                         eng.sync()
                         got = outs_dev[k].cpu().numpy().view(A.RESULT_DTYPE)
@@ -97,8 +108,8 @@ def test_four_threads_one_engine_records_identical_to_serial(oracle):
                         got = eng.verify_batch(p)
                     for f in A.RESULT_DTYPE.names:
                         if f != "reserved" and not (np.asarray(got[f]) == np.asarray(serial[k][f])).all():
-                            raise AssertionError(f"thread {tid} iteration {it}: field {f} differs from the serial run")
-            except Exception as ex:          # noqa: BLE001
+                            raise AssertionError(f"thread {{tid}} iteration {{it}}: field {{f}} differs from the serial run")
+            except Exception as ex:
                 errors.append(repr(ex))
 
         ths = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
@@ -108,8 +119,11 @@ def test_four_threads_one_engine_records_identical_to_serial(oracle):
             t.join(timeout=300)
         assert not errors, errors[:3]
         assert not any(t.is_alive() for t in ths)
-    finally:
         eng.close()
+        print("threads ok")
+    """)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "threads ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
 def test_slot_timings_and_names(oracle):
@@ -147,5 +161,34 @@ def test_single_email_entry_and_larger_than_reserved(oracle):
         (small, _), (big, _) = _batches(1, n=8, seed0=600)[0], _batches(1, n=700, seed0=601)[0]
         for p in (small, big, small):
             assert_records_equal(eng.verify_batch(p), oracle.verify_batch(p, threads=4), None, f"n={p.n}")
+    finally:
+        eng.close()
+
+
+def test_length_buckets_across_slot_reuse(oracle):
+    """The hash stage files bodies and header preimages under length classes (csrc/sha256.hip.h, ShaOrder) and every slot
+    carries its counters from batch to batch (the verdict launch clears them).  One slot, batches that alternate between ragged
+    (3 B .. 40 KB bodies, invalid e-mails, rsa-sha1), uniform and tiny: every record equal to the oracle's every time."""
+    import zkemail_rs_amd as z
+    eng = z.Engine(slots=1)
+    try:
+        shapes = [dict(n=700, body_len=40000, ragged=True, invalid_frac=0.1), dict(n=300, body_len=4096),
+                  dict(n=515, body_len=20000, ragged=True, algo="rsa-sha1"), dict(n=3, body_len=100),
+                  dict(n=1100, body_len=9000, ragged=True, invalid_frac=0.3), dict(n=64, body_len=3)]
+        packs = []
+        for k, sh in enumerate(shapes):
+            wl = synth.make_workload_parallel("buckets", rsa_bits=2048, n_keys=8, seed=700 + k, chunk=256, **sh)
+            p = A.PackedBatch(wl.emails)
+            packs.append((p, oracle.verify_batch(p, threads=8), wl))
+        for rep in range(2):
+            for k, (p, exp, wl) in enumerate(packs):
+                assert_records_equal(eng.verify_batch(p), exp, None, f"pass {rep} shape {k}")
+        # the same through the asynchronous entry, all in flight behind each other in the one slot
+        pending = [(eng.verify_batch_async(p), exp) for p, exp, _ in packs]
+        for (t, out), exp in pending:
+            eng.wait(t)
+            assert_records_equal(out, exp, None, "async")
+        n_ok = int((packs[0][1]["status"] == 0).sum())
+        assert n_ok == sum(1 for it in packs[0][2].inter if it["corrupt"] is None) and 0 < n_ok < 700
     finally:
         eng.close()

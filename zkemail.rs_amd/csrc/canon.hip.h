@@ -51,7 +51,7 @@ struct CanonArgs { BatchDev b; uint32_t mode; uint32_t strict; };
 constexpr uint32_t CANON_LDS_TRASH = 3504, CANON_LDS_BYTES = 3504 + 64;
 static_assert(CANON_LDS_BYTES <= PARSE_STAGE_BYTES, "the front end lends its staging buffer to the canonicaliser");
 __device__ __forceinline__ void canon_body_wave(const BatchDev& B, uint32_t i, uint32_t mode, uint32_t flags, uint32_t boff,
-                                                uint32_t blen, uint64_t len_tag, uint8_t* lds, bool ignore_l) {
+                                                uint32_t blen, uint64_t len_tag, uint8_t* lds, bool ignore_l, bool bucket) {
   const int lane = lane_id();
   EmailMeta* M = B.meta + i;
   zke_result* R = B.results + i;
@@ -295,6 +295,7 @@ __device__ __forceinline__ void canon_body_wave(const BatchDev& B, uint32_t i, u
       ShaJob j; j.src = (uint64_t)(src_is_raw ? body : regB); j.dst = (uint64_t)R->body_hash; j.len = hashed;
       j.pad = (flags & ZKE_F_SHA1) ? 1u : 0u;
       B.sha[i] = j;                             // kind 0
+      if (bucket) sha_bucket(B.order, 0, B.n_pad, i, hashed);
     }
   }
 }
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(64) void canon_body_kernel(CanonArgs A) {
   if (A.mode == 1 && M->reuse) return;
   __shared__ __attribute__((aligned(16))) uint8_t canon_lds[CANON_LDS_BYTES];
   canon_body_wave(B, i, A.mode, M->flags, M->body_off, M->body_len, ((uint64_t)M->len_tag_hi << 32) | M->len_tag_lo, canon_lds,
-                  A.mode == 1 && (A.strict & ZKE_STRICT_CANON_IGNORES_L));
+                  A.mode == 1 && (A.strict & ZKE_STRICT_CANON_IGNORES_L), false);
 }
 
 // ---- verdict of one signature round, by the wave that ran the e-mail's RSA job -----------------------

@@ -78,7 +78,7 @@ struct Slot {
   hipEvent_t ev[MK_N]{};               // timing marks
   uint32_t marks = 0;                  // bit k: ev[k] was recorded for the slot's last timed batch
   zke_timings last{};                  // ... and what they said, once read
-  DevBuf meta, rsa_jobs, sha_jobs, rsa_ok, em_dbg, scratch_off, scratch, clean, meta2, scratch2, parts;
+  DevBuf meta, rsa_jobs, sha_jobs, sha_order, rsa_ok, em_dbg, scratch_off, scratch, clean, meta2, scratch2, parts;
   DevBuf pending;  // device counters: e-mails that need another signature round, the wave-routine job list's length
   // host entry: the packed input image (pinned + HBM), the records (HBM + pinned), the batch not yet delivered
   PinnedBuf h_image, h_results;
@@ -88,8 +88,8 @@ struct Slot {
   uint64_t host_retired = 0;           // ... of which this many have been delivered to their caller's `out`
   zke_result* host_out = nullptr;      // where the pending batch's records go
   uint32_t host_n = 0;
-  DevBuf* all[14] = {&meta, &rsa_jobs, &sha_jobs, &rsa_ok, &em_dbg, &scratch_off, &scratch, &clean, &meta2, &scratch2, &parts, &pending,
-                     &d_image, &d_results};
+  DevBuf* all[15] = {&meta, &rsa_jobs, &sha_jobs, &sha_order, &rsa_ok, &em_dbg, &scratch_off, &scratch, &clean, &meta2, &scratch2, &parts,
+                     &pending, &d_image, &d_results};
   // hipGraph replay of a batch's kernel sequence (zke_options.replay_graphs).  The graph holds this slot's
   // workspace pointers, so it is valid only while none of them has been reallocated: `generation` counts reallocations.
   hipGraphExec_t graph_exec = nullptr;
@@ -208,8 +208,10 @@ int launch_stage(zke_engine* e, const StageArgs& A, hipStream_t s) {
 #define ZKE_WAVE_ROLE_MAX_GROUPS 128     // 256 waves walk the job list: a batch of 1 024 uncached keys takes four rounds of them
 #endif
 int launch_hash_modexp(zke_engine* e, const ShaJob* sha, uint32_t n_sha, const RsaJob* rsa, uint32_t n, EmailMeta* meta,
-                       uint8_t* em_out, uint32_t route_mask, const uint32_t* wave_count, const uint32_t* wave_list, hipStream_t s) {
+                       uint8_t* em_out, uint32_t route_mask, const uint32_t* wave_count, const uint32_t* wave_list, const uint32_t* order,
+                       hipStream_t s) {
   StageArgs A{};
+  A.order = order; A.n_pad = n_sha / 4;
   A.sha = sha; A.n_sha = n_sha; A.rsa = rsa; A.n = n; A.meta = meta;
   A.cache = e->key_cache.as<KeyCacheEntry>();
   A.em_out = em_out;
@@ -223,7 +225,7 @@ int launch_hash_modexp(zke_engine* e, const ShaJob* sha, uint32_t n_sha, const R
     A.g_sha = groups;
     return launch_stage(e, A, s);
   }
-  if (int r = launch_sha(e, sha, n_sha, s)) return r;
+  if (int r = launch_sha(e, sha, n_sha, s)) return r;      // (beyond 512 groups: arrival order; the chip is full either way)
   A.g_sha = 0;
   return launch_stage(e, A, s);
 }

@@ -24,6 +24,7 @@ struct StageArgs {
   const uint32_t* wave_count;              // the front end's list of jobs for the one-signature-per-wave routine (the keys
   const uint32_t* wave_list;               // not cached yet, other exponents ...); nullptr: no list, job = 2 b + wave
   uint32_t g_sha, g_wave, g_quad, g_oct;   // workgroups per role, in this order; blockDim = 128 (two waves)
+  const uint32_t* order; uint32_t n_pad;   // length buckets of the body / header-preimage hashes (BatchDev::order), or nullptr
   uint32_t debug_skip_rsa;
 };
 
@@ -38,7 +39,14 @@ __global__ __launch_bounds__(128, ZKE_STAGE_WAVES) void hash_modexp_kernel(Stage
                 "the RSA roles borrow the launch's LDS");
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
   uint32_t b = blockIdx.x;
-  if (b < A.g_sha) { sha256_pair_group<T>(A.sha, A.n_sha, b, lds_raw); return; }
+  if (b < A.g_sha) {
+    if (!A.order) { sha256_pair_group<T>(A.sha, A.n_sha, b, lds_raw); return; }
+    // kind-major job list: groups [k gpk, (k + 1) gpk) hash kind k; bodies and header preimages by length class
+    const uint32_t gpk = A.n_pad / 64, kind = b / gpk, gk = b - kind * gpk;
+    const ShaOrder so{kind < 2 ? A.order + sha_order_cnt(kind) : nullptr, kind < 2 ? A.order + sha_order_key(kind, A.n_pad) : nullptr, A.n};
+    sha256_pair_group<T>(A.sha + (size_t)kind * A.n_pad, A.n_pad, gk, lds_raw, &so);
+    return;
+  }
   b -= A.g_sha;
   const uint32_t wave = threadIdx.x >> 6;
   if (b < A.g_wave) {

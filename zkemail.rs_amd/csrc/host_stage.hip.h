@@ -10,6 +10,7 @@
 #include <condition_variable>
 #include <functional>
 #include <thread>
+#include <immintrin.h>
 
 namespace {
 
@@ -28,6 +29,30 @@ struct PinnedBuf {
   void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
   template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
+
+// Pageable -> pinned, streaming: non-temporal stores.  An ordinary memcpy of a piece this size reads the destination lines
+// before it overwrites them (read-for-ownership) and leaves the image in the cache hierarchy, where nobody will read it — the
+// DMA engine reads memory.  Streaming stores move two bytes per byte copied instead of three.  dst is 32-byte aligned (pieces
+// start on 64-byte boundaries of a 4 KiB-aligned pinned buffer); the head and tail go through memcpy.
+__attribute__((target("avx2"))) inline void stream_copy_avx2(uint8_t* dst, const uint8_t* src, size_t n) {
+  size_t head = (32 - ((uintptr_t)dst & 31)) & 31;
+  if (head > n) head = n;
+  if (head) { memcpy(dst, src, head); dst += head; src += head; n -= head; }
+  size_t i = 0;
+  for (; i + 128 <= n; i += 128) {
+    const __m256i a = _mm256_loadu_si256((const __m256i*)(src + i)), b = _mm256_loadu_si256((const __m256i*)(src + i + 32)),
+                  c = _mm256_loadu_si256((const __m256i*)(src + i + 64)), d = _mm256_loadu_si256((const __m256i*)(src + i + 96));
+    _mm256_stream_si256((__m256i*)(dst + i), a); _mm256_stream_si256((__m256i*)(dst + i + 32), b);
+    _mm256_stream_si256((__m256i*)(dst + i + 64), c); _mm256_stream_si256((__m256i*)(dst + i + 96), d);
+  }
+  _mm_sfence();
+  if (i < n) memcpy(dst + i, src + i, n - i);
+}
+inline void stage_copy(void* dst, const void* src, size_t n) {
+  static const bool avx2 = __builtin_cpu_supports("avx2");
+  if (avx2 && n >= (64u << 10)) stream_copy_avx2((uint8_t*)dst, (const uint8_t*)src, n);
+  else memcpy(dst, src, n);
+}
 
 // A handful of threads that do nothing but memcpy.  Several callers may use the pool at once (each call waits for its own
 // pieces only); with one thread configured, or for small copies, the caller's thread does the work itself.
@@ -59,7 +84,7 @@ class CopyPool {
     size_t big = 0;
     for (const Piece& p : work) big += p.n >= CHUNK;
     if (threads_.empty() || big < 2) {            // nothing worth sharing
-      for (const Piece& p : work) memcpy(p.dst, p.src, p.n);
+      for (const Piece& p : work) stage_copy(p.dst, p.src, p.n);
       return;
     }
     Job job;
@@ -67,6 +92,7 @@ class CopyPool {
     {
       std::lock_guard<std::mutex> g(mu_);
       for (const Piece& p : work) queue_.push_back(Task{p, &job});
+      pending_.fetch_add((int)work.size(), std::memory_order_release);
     }
     cv_.notify_all();
     // the caller works too: it takes tasks until the queue is empty, then waits for the stragglers
@@ -75,7 +101,7 @@ class CopyPool {
       {
         std::lock_guard<std::mutex> g(mu_);
         if (queue_.empty()) break;
-        t = queue_.back(); queue_.pop_back();
+        t = queue_.back(); queue_.pop_back(); pending_.fetch_sub(1, std::memory_order_relaxed);
       }
       do_task(t);
     }
@@ -87,22 +113,34 @@ class CopyPool {
   struct Job { std::mutex mu; std::condition_variable cv; size_t left = 0; };
   struct Task { Piece p; Job* job; };
   void do_task(const Task& t) {
-    memcpy(t.p.dst, t.p.src, t.p.n);
+    stage_copy(t.p.dst, t.p.src, t.p.n);
     std::lock_guard<std::mutex> g(t.job->mu);
     if (--t.job->left == 0) t.job->cv.notify_all();
   }
   void run() {
     for (;;) {
       Task t;
-      {
+      bool have = false;
+      // A streaming caller hands over the next batch's pieces a few microseconds after the last ones were done: look for them
+      // for a moment before going to sleep (waking a sleeping thread costs more than a piece takes to copy).
+      for (int spin = 0; spin < 4000 && !have; spin++) {
+        if (pending_.load(std::memory_order_acquire)) {
+          std::lock_guard<std::mutex> g(mu_);
+          if (!queue_.empty()) { t = queue_.back(); queue_.pop_back(); pending_.fetch_sub(1, std::memory_order_relaxed); have = true; }
+        } else {
+          _mm_pause();
+        }
+      }
+      if (!have) {
         std::unique_lock<std::mutex> lk(mu_);
         cv_.wait(lk, [&] { return stop_ || !queue_.empty(); });
         if (stop_ && queue_.empty()) return;
-        t = queue_.back(); queue_.pop_back();
+        t = queue_.back(); queue_.pop_back(); pending_.fetch_sub(1, std::memory_order_relaxed);
       }
       do_task(t);
     }
   }
+  std::atomic<int> pending_{0};
   std::vector<std::thread> threads_;
   std::mutex mu_;
   std::condition_variable cv_;

@@ -85,6 +85,8 @@ struct BatchDev {
   uint64_t* scratch_off;      // [n+1]; region A = raw_len + PRE_SLACK bytes, region B = raw_len + 16 (written by the round-0 front end)
   uint64_t* clean_off;        // [n+1]; offsets of the QP-cleaned bodies (regex stage), written alongside
   uint32_t* pending;          // e-mails waiting for another signature round (reset by the round-0 front end)
+  uint32_t* order;            // length buckets of the body and header-preimage hashes (sha256.hip.h, ShaOrder): 2 x 256 counters (zero at
+                              // the start of a batch: the verdict launch of the previous one clears them), then 2 x n_pad keys; or nullptr
   const EmailMeta* meta_verify; // mode 1 only: the verify pass's meta
 };
 constexpr uint32_t PRE_SLACK = 1024;
@@ -1042,7 +1044,12 @@ struct ParseArgs {
 
 // canon.hip.h
 __device__ __forceinline__ void canon_body_wave(const BatchDev& B, uint32_t i, uint32_t mode, uint32_t flags, uint32_t boff,
-                                                uint32_t blen, uint64_t len_tag, uint8_t* lds, bool ignore_l);
+                                                uint32_t blen, uint64_t len_tag, uint8_t* lds, bool ignore_l, bool bucket);
+// File e-mail i's message of `len` bytes (kind 0 body, 1 header preimage) under its length class (one lane).
+__device__ __forceinline__ void sha_bucket(uint32_t* order, uint32_t kind, uint32_t n_pad, uint32_t i, uint32_t len) {
+  const uint32_t cls = sha_len_class((len + 9 + 63) >> 6);
+  order[sha_order_key(kind, n_pad) + i] = (cls << 24) | (atomicAdd(order + sha_order_cnt(kind) + cls, 1u) & 0xFFFFFFu);
+}
 
 
 // The front end of e-mail i by the calling wave (L: the wave's LDS image).  parse_kernel runs it for every e-mail of a
@@ -1096,6 +1103,7 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
   auto finish = [&](uint32_t status, uint32_t detail) {
     if (lane == 0) { M->state = ST_FINAL; M->status = status; M->detail = detail; }
   };
+  const bool bucket = B.order && round == 0 && A.mode == 0;        // (later rounds hash by the e-mail's own wave: verdict.hip.h)
 
   if (A.mode == 1) {
     // canonicalize_signed_email runs only for e-mails whose verify_email succeeded (circuits.rs:32-35)
@@ -1121,6 +1129,7 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
     for (uint32_t o = lane; o < sizeof(zke_result) / 4; o += 64) ((uint32_t*)R)[o] = 0;
     for (uint32_t o = lane; o < sizeof(EmailMeta) / 4; o += 64) ((uint32_t*)M)[o] = 0;
     for (uint32_t k = 0; k < 4; k++) sha_job(k, nullptr, 0, nullptr);
+    if (bucket && lane < 2) B.order[sha_order_key((uint32_t)lane, B.n_pad) + i] = SHA_KEY_NONE;
     if (lane == 0) { J->flags = 0; J->bits = 0; J->k = 0; J->sig_len = 0; J->e = 0; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     if (lane == 0) R->regex_part = 0xFFFFFFFFu;
@@ -1425,6 +1434,7 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
       if (A.mode == 0) { R->flags = flags; R->canon_header_len = out.o; R->sig_index = this_ix; }
     }
     if (A.mode == 0) sha_job(1, regA, out.o, R->header_hash, (flags & ZKE_F_SHA1) ? 1u : 0u);
+    if (bucket && lane == 0) sha_bucket(B.order, 1, B.n_pad, i, out.o);
     if (A.mode == 1) break;
   }
   if (A.mode == 1) {
@@ -1454,7 +1464,7 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
     if ((jf & RSA_F_ACTIVE) && !(jf & (RSA_F_QUAD | RSA_F_OCT)) && A.wave_list) A.wave_list[atomicAdd(A.wave_count, 1u)] = i;
   }
   // ---- body canonicalisation of the candidate (cfdkim hash::compute_body_hash), same wave, no launch boundary
-  canon_body_wave(B, i, 0, cand_flags, body_off, raw.len - body_off, cand_len_tag, L.stage, false);   // parsing is over: the staged head is dead
+  canon_body_wave(B, i, 0, cand_flags, body_off, raw.len - body_off, cand_len_tag, L.stage, false, bucket);   // parsing is over: the staged head is dead
 }
 
 #ifndef ZKE_PARSE_PRIO

@@ -13,6 +13,15 @@ struct StageTimer {
   void mark(int k) { if (on && hipEventRecord(w->ev[k], s) == hipSuccess) w->marks |= 1u << k; }
 };
 
+// Length-bucket counters start a batch at zero (the verdict launch of the slot's previous batch clears them): a fresh
+// allocation is cleared here.
+int ensure_zeroed(DevBuf& b, size_t need) {
+  const void* old = b.p;
+  if (int r = b.ensure(need)) return r;
+  if (b.p != old && hipMemset(b.p, 0, b.cap) != hipSuccess) return ZKE_E_DEVICE;
+  return 0;
+}
+
 // Workspace of one slot for batches of up to n e-mails / raw_total raw bytes (P regex parts; with_regex: the buffers of
 // the canonicalize_signed_email pass too).  Grows only: in steady state — or after zke_engine_reserve — this allocates nothing.
 int ensure_workspace(zke_engine* e, Slot& w, uint32_t n, uint64_t raw_total, bool with_regex, uint32_t P, bool want_em) {
@@ -21,6 +30,7 @@ int ensure_workspace(zke_engine* e, Slot& w, uint32_t n, uint64_t raw_total, boo
   const size_t scratch_bytes = 2 * (size_t)raw_total + (size_t)(n + 1) * SCR_PER_EMAIL + 256;
   if ((r = w.meta.ensure((size_t)n * sizeof(EmailMeta))) || (r = w.rsa_jobs.ensure((size_t)n * sizeof(RsaJob))) ||
       (r = w.sha_jobs.ensure((size_t)4 * n_pad * sizeof(ShaJob))) || (r = w.rsa_ok.ensure((size_t)n * 4)) ||
+      (r = ensure_zeroed(w.sha_order, (size_t)2 * (SHA_ORDER_KIND_WORDS + n_pad) * 4)) ||
       (r = w.scratch_off.ensure((size_t)(n + 1) * 16)) || (r = w.scratch.ensure(scratch_bytes)))
     return fail(e, r, "workspace allocation");
   if (!w.pending.p) {       // counters: [0] e-mails pending another signature round, [2] length of the wave-routine job list (rsa_ok)
@@ -94,6 +104,7 @@ int run_device_pipeline(zke_engine* e, Slot& w, const zke_batch* in, uint64_t ra
   B.clean_off = clean_off;
   B.pending = w.pending.as<uint32_t>();
   B.meta_verify = nullptr;
+  B.order = n < (1u << 24) ? w.sha_order.as<uint32_t>() : nullptr;      // a key holds the position within a class in 24 bits
 
   const uint32_t rounds = e->opt.max_sig_rounds;
   // an RSA-2048 key is 270 bytes of DER: a batch whose keys average more holds some larger modulus
@@ -107,7 +118,7 @@ int run_device_pipeline(zke_engine* e, Slot& w, const zke_batch* in, uint64_t ra
     tm.mark(MK_FRONT);
     // hash / modexp stage: the four SHA-256 jobs and the RSA operation of every e-mail, one launch (fused.hip.h)
     if (!(e->debug_skip_launch & 1) &&
-        (r = launch_hash_modexp(e, B.sha, 4 * n_pad, B.rsa, n, B.meta, want_em ? w.em_dbg.as<uint8_t>() : nullptr, route_mask, wave_count, wave_list, s)))
+        (r = launch_hash_modexp(e, B.sha, 4 * n_pad, B.rsa, n, B.meta, want_em ? w.em_dbg.as<uint8_t>() : nullptr, route_mask, wave_count, wave_list, B.order, s)))
       return r;
     tm.mark(MK_HASH);
     // Ed25519 stage + verdicts (verdict.hip.h): bh compare, EM digest against the header hash, status / detail, pending counter
@@ -308,7 +319,7 @@ int submit_host(zke_engine* e, Slot& w, const zke_batch* in, zke_result* out, bo
         {hp + L.raw, in->raw_blob + in->raw_off[0], (size_t)raw_total}, {hp + L.dom, in->domain_blob + in->domain_off[0], (size_t)dom_total},
         {hp + L.key, in->key_blob + in->key_off[0], (size_t)key_total}, {hp + L.cap_blob, in->cap_blob, caps ? (size_t)cap_bytes : 0}};
     if (e->pool) e->pool->copy(pc, 11);
-    else for (const auto& p : pc) if (p.n) memcpy(p.dst, p.src, p.n);
+    else for (const auto& p : pc) if (p.n) stage_copy(p.dst, p.src, p.n);
   }
   hipStream_t s = w.stream;
   SlotUse use(e, w, s);

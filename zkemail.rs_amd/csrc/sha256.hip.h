@@ -32,6 +32,34 @@ struct ShaJob {          // one message
   uint32_t pad;          // 0: SHA-256; 1: SHA-1 (a=rsa-sha1 signatures; 20-byte digest, slot zero padded)
 };
 
+// ---- length buckets --------------------------------------------------------------------------------------------------
+// A wave hashes 64 messages in lock-step: it runs as many compressions as its LONGEST message needs.  In a ragged batch
+// (body lengths log-uniform over 0 .. 64 KB) 64 messages in arrival order span the whole range, so most lanes of
+// most waves idle for most of the launch.  The front end therefore files every body (and header preimage) under a length
+// class — its block count to three significant bits — with one atomic add: key[i] = class << 24 | position within the class.
+// A hash group lays the classes out longest first (a prefix sum over the 192 counters), finds the 64 messages whose global
+// position falls into its range by one pass over the keys, and hashes messages of one class: no wave waits for a message more
+// than 12.5 % longer than its shortest.  No sort, no extra launch; the digests land by ShaJob::dst, so record order is untouched.
+// Batches whose messages all fall into one or two neighbouring classes (the uniform BASELINE configs) keep the direct
+// mapping lane -> job: the pass over the keys is skipped.
+constexpr uint32_t SHA_CLASSES = 192;               // block counts 1..15 exactly, then 8 classes per octave up to 2^25 blocks
+constexpr uint32_t SHA_ORDER_KIND_WORDS = 256;      // counters of one kind (192 used).  The slot's order buffer: the counters of kind 0,
+                                                    // those of kind 1 — at fixed places, whatever the batch size: they carry over from
+                                                    // batch to batch —, then n_pad keys of kind 0, n_pad keys of kind 1
+__host__ __device__ inline size_t sha_order_cnt(uint32_t kind) { return (size_t)kind * SHA_ORDER_KIND_WORDS; }
+__host__ __device__ inline size_t sha_order_key(uint32_t kind, uint32_t n_pad) { return 2 * (size_t)SHA_ORDER_KIND_WORDS + (size_t)kind * n_pad; }
+constexpr uint32_t SHA_KEY_NONE = 0xFFFFFFFFu;
+__host__ __device__ inline uint32_t sha_len_class(uint32_t nblk) {
+  if (nblk < 16) return nblk;
+  const uint32_t e = 31u - (uint32_t)__builtin_clz(nblk);                  // >= 4
+  return 16u + (e - 4u) * 8u + ((nblk >> (e - 3u)) & 7u);
+}
+struct ShaOrder {                 // one kind's part of the slot's order buffer (nullptr cnt: no buckets, direct mapping)
+  const uint32_t* cnt;            // [SHA_CLASSES] messages per class
+  const uint32_t* key;            // [n] class << 24 | position, SHA_KEY_NONE for an e-mail without a message of this kind
+  uint32_t n;                     // e-mails
+};
+
 __device__ __forceinline__ uint32_t rotr32(uint32_t x, int n) { return __builtin_amdgcn_alignbit(x, x, n); }
 // gfx950 v_bitop3_b32: any 3-input boolean function in one VALU op (truth table in the immediate)
 __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
@@ -264,13 +292,67 @@ constexpr uint32_t SHA_K[64] = {
 constexpr int SHA_KW_ROW = 68;        // dwords per lane and buffer
 
 template <int T>
-constexpr size_t sha256_pair_lds_bytes() { return 64 * (T + 16) + 64 * 16 + 64 * SHA_KW_ROW * 4; }
+constexpr size_t sha256_pair_lds_bytes() { return 64 * (T + 16) + 64 * 16 + 64 * SHA_KW_ROW * 4 + 1024; }      // slab, descriptors, K+W, job pick
+
+// The job of each of a group's 64 lanes under length buckets (see ShaOrder): lane l of group g takes the message at global
+// position 64 g + l of the longest-first order.  `pick`: 1 KB of LDS (192 class bases + 64 picks), written and read by the
+// calling wave only.  Returns the lane's job index within the kind (SHA_KEY_NONE: no message), or `direct` when the batch is
+// uniform enough for the direct mapping.  *skip = the whole group has nothing to do.
+__device__ __forceinline__ uint32_t sha_pick_job(const ShaOrder& O, uint32_t g, uint32_t direct, uint32_t* pick, bool& skip) {
+  const uint32_t lane = threadIdx.x & 63;
+  skip = false;
+  // class bases, longest class first: base[c] = messages in classes above c
+  uint32_t c3[3], tot3 = 0;
+#pragma unroll
+  for (int k = 0; k < 3; k++) { c3[k] = O.cnt[3 * lane + k]; tot3 += c3[k]; }
+  const uint64_t nonempty = __ballot(tot3 != 0);
+  if (!nonempty) { skip = true; return SHA_KEY_NONE; }
+  {
+    // uniform enough?  the non-empty classes span at most two neighbouring ones
+    const uint32_t lo_lane = (uint32_t)__builtin_ctzll(nonempty), hi_lane = 63u - (uint32_t)__builtin_clzll(nonempty);
+    uint32_t lo_c = 0xFFFFFFFFu, hi_c = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) if (c3[k]) { lo_c = min(lo_c, 3 * lane + k); hi_c = max(hi_c, 3 * lane + k); }
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)lo_c, (int)lo_lane), hi = (uint32_t)__builtin_amdgcn_readlane((int)hi_c, (int)hi_lane);
+    if (hi - lo <= 1) return direct;
+  }
+  uint32_t above = tot3;                                   // inclusive suffix sum over the lanes: messages in this lane's classes and above
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_down((int)above, o); if (lane + o < 64) above += t; }
+  const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane((int)above);
+  if (64 * g >= total) { skip = true; return SHA_KEY_NONE; }
+  uint32_t b = above - tot3;                               // messages in the classes above this lane's
+  pick[3 * lane + 2] = b; b += c3[2];
+  pick[3 * lane + 1] = b; b += c3[1];
+  pick[3 * lane + 0] = b;
+  pick[SHA_CLASSES + lane] = SHA_KEY_NONE;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t lo = 64 * g;
+  for (uint32_t t0 = 0; t0 < O.n; t0 += 256) {             // four keys per lane and step: the loads of a step are in flight together
+    uint32_t k4[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) { const uint32_t i = t0 + 64 * q + lane; k4[q] = i < O.n ? O.key[i] : SHA_KEY_NONE; }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      if (k4[q] != SHA_KEY_NONE) {
+        const uint32_t gp = pick[k4[q] >> 24] + (k4[q] & 0xFFFFFFu) - lo;
+        if (gp < 64) pick[SHA_CLASSES + gp] = t0 + 64 * q + lane;
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  return pick[SHA_CLASSES + lane];
+}
 
 // The two waves of workgroup-local threads 0..127 hash messages [64 group, 64 group + 64); lds_raw: sha256_pair_lds_bytes<T>()
 // of 16-byte aligned LDS.  A device routine so that other work can share the launch (fused.hip.h); both waves of the
 // workgroup must call it (it uses __syncthreads()).
+// `order`: length buckets of the jobs [0, n) this call sees (then `jobs` / `n` / `group` are the kind's), or nullptr.
 template <int T>
-__device__ __forceinline__ void sha256_pair_group(const ShaJob* __restrict__ jobs, uint32_t n, uint32_t group, uint8_t* lds_raw) {
+__device__ __forceinline__ void sha256_pair_group(const ShaJob* __restrict__ jobs, uint32_t n, uint32_t group, uint8_t* lds_raw,
+                                                  const ShaOrder* order = nullptr) {
   static_assert(T % 64 == 0 && T >= 64 && T <= 1024, "tile must be whole SHA blocks");
   constexpr int ROW = T + 16;
   constexpr int LPR = T / 16;
@@ -284,8 +366,24 @@ __device__ __forceinline__ void sha256_pair_group(const ShaJob* __restrict__ job
   uint8_t* slab = lds_raw;
   uint8_t* desc = slab + 64 * ROW;
   uint32_t* kw = (uint32_t*)(desc + 64 * 16);      // [64 lanes][SHA_KW_ROW]: a lane's 64 words are contiguous (b128 accesses)
+  uint32_t* pick = kw + 64 * SHA_KW_ROW;           // 1 KB: sha_pick_job
 
-  const uint32_t m = group * 64 + lane;            // both waves look at the same 64 jobs
+  uint32_t m = group * 64 + lane;                  // both waves look at the same 64 jobs
+  if (order && order->cnt) {
+    // length buckets: the feeder works the picks out, the rounds wave reads them (one barrier; every thread of the group
+    // arrives here, and a group with nothing to do leaves as a whole)
+    bool skip = false;
+    uint32_t mine = 0;
+    if (role == 0) {
+      mine = sha_pick_job(*order, group, m, pick, skip);
+      if (lane == 0) pick[SHA_CLASSES - 1] = skip ? 1u : 0u;          // (class 191 = 2^25 blocks and more: never populated)
+      pick[SHA_CLASSES + lane] = mine;
+    }
+    __syncthreads();
+    if (pick[SHA_CLASSES - 1]) return;
+    m = pick[SHA_CLASSES + lane];
+    __syncthreads();                               // the pick area is dead from here (nobody writes it again)
+  }
   uint64_t my_src = 0, my_dst = 0;
   uint32_t my_len = 0, my_nblk = 0, my_algo = 0;
   if (m < n) {

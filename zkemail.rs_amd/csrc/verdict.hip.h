@@ -105,6 +105,9 @@ __global__ __launch_bounds__(64, ZKE_VERDICT_WAVES) void ed_verdict_kernel(EdVer
   const int lane = threadIdx.x & 63;
   const uint32_t base = blockIdx.x * VERDICT_EMAILS_PER_WAVE;
   if (blockIdx.x == 0 && lane == 0 && A.wave_count) *A.wave_count = 0;
+  if (blockIdx.x == 0 && B.order)              // the hash stage has consumed the length buckets: counters back to zero for the slot's next batch
+    for (uint32_t k = 0; k < 2; k++)
+      for (uint32_t c = (uint32_t)lane; c < SHA_CLASSES; c += 64) B.order[sha_order_cnt(k) + c] = 0;
   FinArgs fin = A.fin;
   uint64_t active = 0;                                  // verdict lanes (= e-mails base + lane) this wave still works on
   for (uint32_t j = 0; j < VERDICT_EMAILS_PER_WAVE; j++) if (base + j < B.n) active |= 1ull << j;
