@@ -42,16 +42,16 @@ __device__ __forceinline__ uint32_t trailing_crlf_pairs(LD load, uint32_t len, b
   return matched / 2;
 }
 
-struct CanonArgs { BatchDev b; uint32_t mode; uint32_t strict; };
-
 // Canonicalise the body of e-mail i with the calling wave.  `flags`, `boff`, `blen` and the l= value are handed
 // over in registers: the wave-per-e-mail front end calls this right after it has chosen the candidate signature
-// (no launch boundary, no trip through EmailMeta); the stand-alone kernel below reads them from EmailMeta.
+// (no launch boundary, no trip through EmailMeta); regex_prep_kernel (regex.hip.h) reads them from EmailMeta for the rare
+// e-mail whose canonicalize_signed_email pass cannot reuse the verify pass.
 // `lds`: CANON_LDS_BYTES of 16-byte aligned LDS the wave may overwrite (the front end hands over its staging buffer).
 constexpr uint32_t CANON_LDS_TRASH = 3504, CANON_LDS_BYTES = 3504 + 64;
 static_assert(CANON_LDS_BYTES <= PARSE_STAGE_BYTES, "the front end lends its staging buffer to the canonicaliser");
 __device__ __forceinline__ void canon_body_wave(const BatchDev& B, uint32_t i, uint32_t mode, uint32_t flags, uint32_t boff,
-                                                uint32_t blen, uint64_t len_tag, uint8_t* lds, bool ignore_l, bool bucket) {
+                                                uint32_t blen, uint64_t len_tag, uint8_t* lds, bool ignore_l, bool bucket,
+                                                uint32_t hdr_len) {
   const int lane = lane_id();
   EmailMeta* M = B.meta + i;
   zke_result* R = B.results + i;
@@ -295,22 +295,9 @@ __device__ __forceinline__ void canon_body_wave(const BatchDev& B, uint32_t i, u
       ShaJob j; j.src = (uint64_t)(src_is_raw ? body : regB); j.dst = (uint64_t)R->body_hash; j.len = hashed;
       j.pad = (flags & ZKE_F_SHA1) ? 1u : 0u;
       B.sha[i] = j;                             // kind 0
-      if (bucket) sha_bucket(B.order, 0, B.n_pad, i, hashed);
     }
   }
-}
-
-// stand-alone launch: the canonicalize_signed_email pass (mode 1)
-__global__ __launch_bounds__(64) void canon_body_kernel(CanonArgs A) {
-  const BatchDev& B = A.b;
-  const uint32_t i = blockIdx.x;
-  if (i >= B.n) return;
-  const EmailMeta* M = B.meta + i;
-  if (M->state != ST_CAND) return;
-  if (A.mode == 1 && M->reuse) return;
-  __shared__ __attribute__((aligned(16))) uint8_t canon_lds[CANON_LDS_BYTES];
-  canon_body_wave(B, i, A.mode, M->flags, M->body_off, M->body_len, ((uint64_t)M->len_tag_hi << 32) | M->len_tag_lo, canon_lds,
-                  A.mode == 1 && (A.strict & ZKE_STRICT_CANON_IGNORES_L), false);
+  if (bucket && lane < 2) sha_bucket(B.order, (uint32_t)lane, B.n_pad, i, lane ? hdr_len : hashed);      // body and header preimage
 }
 
 // ---- verdict of one signature round, by the wave that ran the e-mail's RSA job -----------------------

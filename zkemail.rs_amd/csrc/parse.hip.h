@@ -1044,8 +1044,11 @@ struct ParseArgs {
 
 // canon.hip.h
 __device__ __forceinline__ void canon_body_wave(const BatchDev& B, uint32_t i, uint32_t mode, uint32_t flags, uint32_t boff,
-                                                uint32_t blen, uint64_t len_tag, uint8_t* lds, bool ignore_l, bool bucket);
-// File e-mail i's message of `len` bytes (kind 0 body, 1 header preimage) under its length class (one lane).
+                                                uint32_t blen, uint64_t len_tag, uint8_t* lds, bool ignore_l, bool bucket,
+                                                uint32_t hdr_len = 0);
+// File e-mail i's message of `len` bytes (kind 0 body, 1 header preimage) under its length class.  One lane per kind: lanes 0
+// and 1 file the body and the header preimage with ONE atomic instruction at the very end of the front end — the positions
+// come back after a round trip to the memory side that nothing else waits for.
 __device__ __forceinline__ void sha_bucket(uint32_t* order, uint32_t kind, uint32_t n_pad, uint32_t i, uint32_t len) {
   const uint32_t cls = sha_len_class((len + 9 + 63) >> 6);
   order[sha_order_key(kind, n_pad) + i] = (cls << 24) | (atomicAdd(order + sha_order_cnt(kind) + cls, 1u) & 0xFFFFFFu);
@@ -1055,7 +1058,7 @@ __device__ __forceinline__ void sha_bucket(uint32_t* order, uint32_t kind, uint3
 // The front end of e-mail i by the calling wave (L: the wave's LDS image).  parse_kernel runs it for every e-mail of a
 // batch (round 0, and mode 1); the verdict launch runs it again, round by round, for the rare e-mail whose candidate
 // signature failed while a later same-domain signature is still untried (verdict.hip.h).
-template <bool FAST = true>
+template <bool FAST = true, int MODE = 0>
 __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i, ParseLds& L) {
   const BatchDev& B = A.b;
   const int lane = lane_id();
@@ -1063,7 +1066,7 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
   zke_result* R = B.results + i;
   RsaJob* J = B.rsa + i;
   const uint32_t round = A.round;
-  if (round > 0 && A.mode == 0) {
+  if (round > 0 && MODE == 0) {
     // later signature rounds: retire this e-mail's jobs of the previous round first, so the SHA / RSA
     // launches of this round only touch e-mails that are still pending
     if (lane < 4) { ShaJob z{0, 0, 0, 0}; B.sha[(size_t)lane * B.n_pad + i] = z; }
@@ -1072,9 +1075,9 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
   }
 
   const uint64_t r0 = B.raw_off[i], r1 = B.raw_off[i + 1];
-  if (round == 0 && A.mode == 0) batch_prologue(B, i, lane == 0, i == 0, (uint32_t)lane, 64);
+  if (round == 0 && MODE == 0) batch_prologue(B, i, lane == 0, i == 0, (uint32_t)lane, 64);
   Str raw = mkstr(B.raw + r0, (uint32_t)(r1 - r0));
-  {
+  auto stage_head = [&]() {
     // Stage the head of the e-mail in LDS with 16-byte lane-contiguous loads: every later scan of the header
     // block (split, tag lists, canonicalisation) then costs LDS latency instead of a dependent L2 round trip.
     const uint32_t want = raw.len < PARSE_STAGE_BYTES ? raw.len : PARSE_STAGE_BYTES;
@@ -1087,15 +1090,15 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     raw.lds = L.stage; raw.lds_len = want;
-  }
-  ZKE_DEV_STOP(1);
+  };
+  if (MODE == 0) stage_head();
   const Str dom = mkstr(B.dom + B.dom_off[i], (uint32_t)(B.dom_off[i + 1] - B.dom_off[i]));
   const Str key = mkstr(B.key + B.key_off[i], (uint32_t)(B.key_off[i + 1] - B.key_off[i]));
   uint8_t* regA = B.scratch + scratch_offset(r0 - B.raw_off[0], i);
   const uint32_t capA = raw.len + PRE_SLACK;
 
   auto sha_job = [&](uint32_t kind, const void* src, uint32_t len, void* dst, uint32_t algo = 0) {
-    if (lane == 0 && A.mode == 0) {
+    if (lane == 0 && MODE == 0) {
       ShaJob j; j.src = (uint64_t)src; j.dst = (uint64_t)dst; j.len = len; j.pad = algo;
       B.sha[(size_t)kind * B.n_pad + i] = j;
     }
@@ -1103,9 +1106,9 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
   auto finish = [&](uint32_t status, uint32_t detail) {
     if (lane == 0) { M->state = ST_FINAL; M->status = status; M->detail = detail; }
   };
-  const bool bucket = B.order && round == 0 && A.mode == 0;        // (later rounds hash by the e-mail's own wave: verdict.hip.h)
+  const bool bucket = B.order && round == 0 && MODE == 0;        // (later rounds hash by the e-mail's own wave: verdict.hip.h)
 
-  if (A.mode == 1) {
+  if (MODE == 1) {
     // canonicalize_signed_email runs only for e-mails whose verify_email succeeded (circuits.rs:32-35)
     for (uint32_t o = lane; o < sizeof(EmailMeta) / 4; o += 64) ((uint32_t*)M)[o] = 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1136,6 +1139,8 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
     if (r1 - r0 >= (1ull << 31)) { finish(ZKE_UNSUPPORTED, ZKE_D_U_EMAIL_TOO_LARGE); return; }
   }
 
+  if (MODE == 1) stage_head();      // (after the early exits above: an e-mail whose canonicalize pass reuses the verify pass never gets here)
+  ZKE_DEV_STOP(1);
   // ---- mailparse::parse_mail (core/src/email.rs:26)
   uint32_t perr;
   uint32_t hdr_end = 0;
@@ -1151,13 +1156,13 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
   const uint32_t body_off = find_body(raw, hdr_end >= 2 ? hdr_end - 2 : 0);
   ZKE_DEV_STOP(3);
   if (lane == 0) {
-    if (A.mode == 0) { R->n_headers = nh; R->body_offset = body_off; }
+    if (MODE == 0) { R->n_headers = nh; R->body_offset = body_off; }
     M->n_headers = nh; M->body_off = body_off; M->body_len = raw.len - body_off;
   }
   // lane x: where header field x's name starts and how long it is (fields 0..63; later ones are looked up one by one)
   uint32_t hks_lane = 0, hnl_lane = NONE;
   if ((uint32_t)lane < nh && lane < (int)HDR_LDS_ENTRIES) { hks_lane = L.hdr[4 * lane]; hnl_lane = L.hdr[4 * lane + 1] - hks_lane; }
-  if (round == 0 && A.mode == 0) {
+  if (round == 0 && MODE == 0) {
     // ---- still parse_mail: the MIME subparts (mime.hip.h).  The first Content-Type header of the message decides.
     bool has_ct = false;
     uint32_t cvs = 0, cve = 0;
@@ -1179,7 +1184,7 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
   }
 
   // ---- DkimPublicKey::try_from_bytes (core/src/email.rs:28-29)
-  if (round == 0 && A.mode == 0) {
+  if (round == 0 && MODE == 0) {
     const uint32_t kt = B.key_type[i];
     if (kt == ZKE_KEY_ED25519) {
       // raw 32 bytes (helpers/src/dkim.rs:103-108); whether they are a curve point is decided by ed25519_email_kernel
@@ -1218,7 +1223,7 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
   uint32_t err_after = 0;      // last non-candidate error after this round's candidate
   bool have_cand = false;
   uint32_t first_sig_hdr = NONE;
-  uint32_t cand_flags = 0;
+  uint32_t cand_flags = 0, cand_hdr_len = 0;
   uint64_t cand_len_tag = 0;
   const uint64_t sig_len_mask = __ballot(hnl_lane == 14u);          // only a 14-byte name can be "DKIM-Signature"
   for (uint32_t hx = 0; hx < nh; hx++) {
@@ -1228,7 +1233,7 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
     if (!span_ieq(raw, ks, ke - ks, LIT("dkim-signature"))) continue;
     const uint32_t this_ix = sig_ix++;
     if (first_sig_hdr == NONE) first_sig_hdr = hx;
-    if (A.mode == 1 && hx != first_sig_hdr) break;
+    if (MODE == 1 && hx != first_sig_hdr) break;
     const Str v = substr(raw, vs, ve);
     auto note_err = [&](uint32_t e) { err_all = e; if (have_cand) err_after = e; last_touched = this_ix; };
     uint32_t present;
@@ -1236,15 +1241,15 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
     ZKE_DEV_STOP(5);
     if (verr == ZKE_D_U_SIG_NON_ASCII || verr == ZKE_D_U_TOO_MANY_TAGS || verr == ZKE_D_U_SIG_TOO_LONG) {
       unsupported = verr; last_touched = this_ix;
-      if (A.mode == 1) { finish(ZKE_UNSUPPORTED, verr); return; }
+      if (MODE == 1) { finish(ZKE_UNSUPPORTED, verr); return; }
       continue;
     }
     if (verr) {
-      if (A.mode == 1) { finish(ZKE_CANON_FAIL, verr); return; }
+      if (MODE == 1) { finish(ZKE_CANON_FAIL, verr); return; }
       note_err(verr);
       continue;
     }
-    if (A.mode == 0) {
+    if (MODE == 0) {
       // signing_domain.to_lowercase() == from_domain.to_lowercase()
       bool same = tagf(L, TG_D, 3) == dom.len;
       if (same) {
@@ -1268,11 +1273,11 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
       else if (c == LIT("simple/simple") || c == LIT("simple")) flags = 0;
       else if (c == LIT("simple/relaxed")) flags = ZKE_F_BODY_RELAXED;
       else {
-        if (A.mode == 1) { finish(ZKE_CANON_FAIL, ZKE_D_BAD_CANON); return; }
+        if (MODE == 1) { finish(ZKE_CANON_FAIL, ZKE_D_BAD_CANON); return; }
         note_err(ZKE_D_BAD_CANON); continue;
       }
     }
-    if (A.mode == 0) {
+    if (MODE == 0) {
       bool ed_alg = false;
       const TagVal a = tagval(L, TG_A);
       if (a == LIT("rsa-sha256")) {}
@@ -1286,7 +1291,7 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
     uint64_t len_tag = 0;
     if (present & (1u << TG_L)) {
       if (!parse_usize_tag(L, TG_L, len_tag)) {
-        if (A.mode == 1) { finish(ZKE_CANON_FAIL, ZKE_D_BAD_LENGTH); return; }
+        if (MODE == 1) { finish(ZKE_CANON_FAIL, ZKE_D_BAD_LENGTH); return; }
         note_err(ZKE_D_BAD_LENGTH); continue;
       }
       flags |= ZKE_F_HAS_LENGTH;
@@ -1298,7 +1303,7 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
 
     // ---- the b= value: decode, and locate its raw span for removal from the preimage
     const uint32_t b_rs = tagf(L, TG_B, 0), b_re = tagf(L, TG_B, 1);
-    if (A.mode == 0) {
+    if (MODE == 0) {
       uint32_t sig_len = 0;
       const bool b64ok = decode_sig(L, tagf(L, TG_B, 2), tagf(L, TG_B, 3), J, sig_len);
       const uint32_t bh_o = tagf(L, TG_BH, 2), bh_l = tagf(L, TG_BH, 3);
@@ -1422,7 +1427,7 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
     else { emit_lit(out, LIT("DKIM-Signature: ")); emit_map(out, sv, 0, sv.len, [](uint32_t c) { return c; }); }
     if (out.overflow) {
       unsupported = ZKE_D_U_PREIMAGE_OVERFLOW;
-      if (A.mode == 1) { finish(ZKE_UNSUPPORTED, unsupported); return; }
+      if (MODE == 1) { finish(ZKE_UNSUPPORTED, unsupported); return; }
       have_cand = false; cand_count--;
       continue;
     }
@@ -1431,13 +1436,13 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
       M->cand_sig_index = this_ix; M->cand_hdr = hx; M->flags = flags;
       M->len_tag_lo = (uint32_t)len_tag; M->len_tag_hi = (uint32_t)(len_tag >> 32);
       M->preimage_len = out.o;
-      if (A.mode == 0) { R->flags = flags; R->canon_header_len = out.o; R->sig_index = this_ix; }
+      if (MODE == 0) { R->flags = flags; R->canon_header_len = out.o; R->sig_index = this_ix; }
     }
-    if (A.mode == 0) sha_job(1, regA, out.o, R->header_hash, (flags & ZKE_F_SHA1) ? 1u : 0u);
-    if (bucket && lane == 0) sha_bucket(B.order, 1, B.n_pad, i, out.o);
-    if (A.mode == 1) break;
+    if (MODE == 0) sha_job(1, regA, out.o, R->header_hash, (flags & ZKE_F_SHA1) ? 1u : 0u);
+    cand_hdr_len = out.o;
+    if (MODE == 1) break;
   }
-  if (A.mode == 1) {
+  if (MODE == 1) {
     if (!have_cand) { finish(ZKE_CANON_FAIL, first_sig_hdr == NONE ? ZKE_D_NO_SIGNATURE : ZKE_D_SIG_SYNTAX); return; }
     if (lane == 0) { M->state = ST_CAND; M->first_sig_hdr = first_sig_hdr; }
     return;
@@ -1464,14 +1469,15 @@ __device__ __forceinline__ void parse_email(const ParseArgs& A, const uint32_t i
     if ((jf & RSA_F_ACTIVE) && !(jf & (RSA_F_QUAD | RSA_F_OCT)) && A.wave_list) A.wave_list[atomicAdd(A.wave_count, 1u)] = i;
   }
   // ---- body canonicalisation of the candidate (cfdkim hash::compute_body_hash), same wave, no launch boundary
-  canon_body_wave(B, i, 0, cand_flags, body_off, raw.len - body_off, cand_len_tag, L.stage, false, bucket);   // parsing is over: the staged head is dead
+  canon_body_wave(B, i, 0, cand_flags, body_off, raw.len - body_off, cand_len_tag, L.stage, false, bucket, cand_hdr_len);   // parsing is over: the staged head is dead
 }
 
 #ifndef ZKE_PARSE_PRIO
 #define ZKE_PARSE_PRIO 0
 #endif
 #ifndef ZKE_PARSE_WAVES
-#define ZKE_PARSE_WAVES 6        // waves per SIMD the front end is compiled for (LDS allows 23 per CU)
+#define ZKE_PARSE_WAVES 5        // waves per SIMD the front end is compiled for: 96 registers, no spills (at 6 — 80 registers — it spills 300 B per
+                                 // lane since the strictness sites and the length buckets joined it: 28.5 M e-mails/s against 30.1 M; LDS allows 22 waves per CU)
 #endif
 // ZKE_PARSE_WG_WAVES = W: W e-mails per workgroup, still one per wavefront and nothing shared between them (no barrier,
 // an LDS area each).  W only sets the granularity at which the chip hands out LDS and registers to the front end: with

@@ -74,7 +74,7 @@ int raise_dfa_lds_attrs(zke_engine* e, size_t lds) {
 // rounds of the rare e-mail that needs them) — and, for verify_email_with_regex, the regex stage behind them.
 // Caller holds the slot's lock; everything the call needs is in its arguments or in the slot.
 int run_device_pipeline(zke_engine* e, Slot& w, const zke_batch* in, uint64_t raw_total, uint64_t key_total, zke_result* out_dev,
-                        hipStream_t s, bool want_em, uint64_t now) {
+                        hipStream_t s, bool want_em, uint64_t now, bool want_clean = false) {
   const uint32_t n = in->n;
   if (n == 0) return 0;
   const uint32_t n_pad = (n + 63) & ~63u;
@@ -148,17 +148,18 @@ int run_device_pipeline(zke_engine* e, Slot& w, const zke_batch* in, uint64_t ra
         parts[p] = pi;
       }
     }
-    // canonicalize_signed_email (circuits.rs:34-35): first DKIM-Signature header, own scratch unless it is the verified one
+    // canonicalize_signed_email (circuits.rs:34-35: first DKIM-Signature header, own scratch unless it is the verified one) and
+    // remove_quoted_printable_soft_breaks (circuits.rs:37), one launch (regex.hip.h, regex_prep_kernel).  The cleaned body is
+    // unobservable without body parts (circuits.rs:48-56): it is then only produced when a parity buffer asks for it.
     BatchDev B2 = B;
     B2.meta = w.meta2.as<EmailMeta>();
     B2.scratch = w.scratch2.as<uint8_t>();
     B2.meta_verify = B.meta;
-    ParseArgs pa{B2, 0, 1, 0, e->strict, now, nullptr, 0, nullptr, nullptr};
-    hipLaunchKernelGGL(parse_kernel, dim3((n + ZKE_PARSE_WG_WAVES - 1) / ZKE_PARSE_WG_WAVES), dim3(64 * ZKE_PARSE_WG_WAVES), PARSE_DYN_LDS, s, pa);
-    CanonArgs ca{B2, 1, e->strict};
-    hipLaunchKernelGGL(canon_body_kernel, dim3(n), dim3(64), 0, s, ca);
-    QpArgs qa{B2, B.meta, w.clean.as<uint8_t>(), clean_off, B.scratch, B.scratch_off};
-    hipLaunchKernelGGL(qp_kernel, dim3(n), dim3(64), 0, s, qa);    // circuits.rs:37 runs whether or not body parts exist
+    B2.order = nullptr;
+    PrepArgs pr{ParseArgs{B2, 0, 1, 0, e->strict, now, nullptr, 0, nullptr, nullptr},
+                QpArgs{B2, B.meta, w.clean.as<uint8_t>(), clean_off, B.scratch, B.scratch_off},
+                (in->n_body_parts || want_clean) ? 1u : 0u};
+    hipLaunchKernelGGL(regex_prep_kernel, dim3(n), dim3(64), 0, s, pr);
     tm.mark(MK_PREP);
     DfaArgs base{};
     base.b = B2; base.P = P;
@@ -178,35 +179,36 @@ int run_device_pipeline(zke_engine* e, Slot& w, const zke_batch* in, uint64_t ra
     // against 12.7 M with the wave kernel; 1 024 per batch 11.4 M against 11.8 M).  zke_options.dfa_mapping forces one.
     const uint32_t wave_from = e->opt.dfa_mapping == 1 ? P : e->opt.dfa_mapping == 2 ? 0u
                              : (n <= 1024 ? 0u : in->n_header_parts);      // parts [wave_from, P) use the wave kernel
-    if (wave_from < P) {
-      // one e-mail per wave; up to DFA_MULTI_MAX parts per launch (grid.y)
-      for (uint32_t p0 = wave_from; p0 < P; p0 += DFA_MULTI_MAX) {
-        const uint32_t np = std::min<uint32_t>(DFA_MULTI_MAX, P - p0);
-        DfaMultiArgs ma{};
-        ma.common = base; ma.part0 = p0; ma.n_header_parts = in->n_header_parts;
-        size_t lds = 1024;
-        for (uint32_t k = 0; k < np; k++) {
-          const PartInfo& pi = parts[p0 + k];
-          ma.re[k] = pi.dev;
-          lds = std::max(lds, part_lds(pi, ma.lds_tables[k]));
-          ma.idle[k] = pi.dev ? pi.idle : 0xFFFFFFFFu;
-          ma.detail[k] = pi.detail;
-        }
-        hipLaunchKernelGGL(dfa_wave_kernel, dim3((n + 3) / 4, np), dim3(256), lds, s, ma);
+    // Parts in order, up to DFA_MULTI_MAX per launch (grid.y): [0, wave_from) one e-mail per lane, [wave_from, P) one e-mail per
+    // wave.  A last launch that holds ONE part also writes the regex verdict into the records (it folds the earlier launches'
+    // parts first); otherwise the verdict is a small launch of its own behind them.  (The parts of a launch run side by side:
+    // walking them one after the other inside a block, verdict folded in, was measured — configs[4] shape 10.2 M e-mails/s
+    // against 11.9 M, its dfa stage 505 us alone against 387.)
+    bool folded = false;
+    for (uint32_t p0 = 0; p0 < P;) {
+      const bool lane_kernel = p0 < wave_from;
+      const uint32_t end = lane_kernel ? wave_from : P;
+      const uint32_t np = std::min<uint32_t>(DFA_MULTI_MAX, end - p0);
+      DfaMultiArgs ma{};
+      ma.common = base; ma.part0 = p0; ma.np = np; ma.n_header_parts = in->n_header_parts;
+      ma.finalize = (p0 + np >= P && np == 1) ? 1u : 0u;
+      folded = ma.finalize != 0;
+      size_t lds = 1024;
+      for (uint32_t k = 0; k < np; k++) {
+        const PartInfo& pi = parts[p0 + k];
+        ma.re[k] = pi.dev;
+        lds = std::max(lds, part_lds(pi, ma.lds_tables[k]));
+        ma.idle[k] = (pi.dev && !lane_kernel) ? pi.idle : 0xFFFFFFFFu;
+        ma.detail[k] = pi.detail;
       }
+      if (lane_kernel) hipLaunchKernelGGL(dfa_kernel, dim3((n + 255) / 256, np), dim3(256), lds, s, ma);
+      else hipLaunchKernelGGL(dfa_wave_kernel, dim3((n + 3) / 4, np), dim3(256), lds, s, ma);
+      p0 += np;
     }
-    for (uint32_t p = 0; p < wave_from; p++) {               // one e-mail per lane, one launch per part
-      const PartInfo& pi = parts[p];
-      DfaArgs da = base;
-      da.re = pi.dev;
-      da.part = p; da.is_body = p >= in->n_header_parts ? 1 : 0;
-      const size_t lds = part_lds(pi, da.lds_tables);
-      da.idle = 0xFFFFFFFFu;
-      da.decode_detail = pi.detail;
-      hipLaunchKernelGGL(dfa_kernel, dim3((n + 255) / 256), dim3(256), lds, s, da);
+    if (!folded) {
+      RegexFinArgs rf{B2, w.parts.as<PartRes>(), in->n_header_parts, in->n_body_parts};
+      hipLaunchKernelGGL(regex_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, s, rf);
     }
-    RegexFinArgs rf{B2, w.parts.as<PartRes>(), in->n_header_parts, in->n_body_parts};
-    hipLaunchKernelGGL(regex_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, s, rf);
     tm.mark(MK_DFA);
     HIPCHK(e, hipGetLastError());
   }
@@ -295,7 +297,7 @@ int retire_host(zke_engine* e, Slot& w) {
 }
 
 // One host-memory batch into slot w (caller holds its lock): pack -> one H2D -> the launches -> one D2H -> event.
-int submit_host(zke_engine* e, Slot& w, const zke_batch* in, zke_result* out, bool want_em, ImageLayout* layout_out) {
+int submit_host(zke_engine* e, Slot& w, const zke_batch* in, zke_result* out, bool want_em, bool want_clean) {
   const uint32_t n = in->n;
   const uint64_t raw_total = in->raw_off[n] - in->raw_off[0], dom_total = in->domain_off[n] - in->domain_off[0],
                  key_total = in->key_off[n] - in->key_off[0];
@@ -304,7 +306,6 @@ int submit_host(zke_engine* e, Slot& w, const zke_batch* in, zke_result* out, bo
   const uint32_t n_caps = caps ? in->cap_off[(size_t)n * P] : 0;
   const uint32_t cap_bytes = caps ? in->cap_str_off[n_caps] : 0;
   const ImageLayout L = image_layout(n, raw_total, dom_total, key_total, caps ? (size_t)n * P + 1 : 0, caps ? (size_t)n_caps + 1 : 0, cap_bytes);
-  if (layout_out) *layout_out = L;
   if (int r = retire_host(e, w)) return r;           // the pinned buffers are about to be overwritten
   if (int r = ensure_host_buffers(e, w, L.total, n)) return r;
   uint8_t* hp = w.h_image.as<uint8_t>();
@@ -341,7 +342,7 @@ int submit_host(zke_engine* e, Slot& w, const zke_batch* in, zke_result* out, bo
   dv.cap_off = caps ? reinterpret_cast<const uint32_t*>(dp + L.cap_off) : nullptr;
   dv.cap_str_off = caps ? reinterpret_cast<const uint32_t*>(dp + L.cap_str_off) : nullptr;
   dv.cap_blob = caps ? dp + L.cap_blob : nullptr;
-  if (int r = run_device_pipeline(e, w, &dv, raw_total, key_total, w.d_results.as<zke_result>(), s, want_em, batch_clock(e))) return r;
+  if (int r = run_device_pipeline(e, w, &dv, raw_total, key_total, w.d_results.as<zke_result>(), s, want_em, batch_clock(e), want_clean)) return r;
   HIPCHK(e, hipMemcpyAsync(w.h_results.p, w.d_results.p, (size_t)n * sizeof(zke_result), hipMemcpyDeviceToHost, s));
   tm.mark(MK_D2H);
   HIPCHK(e, hipEventRecord(w.host_done, s));
@@ -654,7 +655,7 @@ int zke_verify_batch_async(zke_engine* e, const zke_batch* in, zke_result* out, 
   Slot& w = next_slot(e, slot);
   std::lock_guard<std::mutex> g(w.mu);
   if (in->n == 0) { *ticket = make_ticket(slot, w.host_retired); return 0; }      // nothing to wait for
-  if (int r = submit_host(e, w, in, out, false, nullptr)) return r;
+  if (int r = submit_host(e, w, in, out, false, false)) return r;
   *ticket = make_ticket(slot, w.host_gen);
   return 0;
 }
@@ -682,7 +683,7 @@ int zke_verify_batch(zke_engine* e, const zke_batch* in, zke_result* out, zke_de
   Slot& w = next_slot(e, slot);
   std::lock_guard<std::mutex> g(w.mu);
   const bool want_em = dbg && dbg->em;
-  if (int r = submit_host(e, w, in, out, want_em, nullptr)) return r;
+  if (int r = submit_host(e, w, in, out, want_em, dbg && dbg->clean_body)) return r;
   if (int r = retire_host(e, w)) return r;
   if (!dbg) return 0;
 

@@ -45,24 +45,9 @@ __device__ __forceinline__ const uint8_t* region_b(const uint8_t* scratch, const
   return scratch + off[i] + (((size_t)raw_len + PRE_SLACK + 15) & ~(size_t)15);
 }
 
-// The canonical body of e-mail i as canonicalize_signed_email returns it (after l=)
-__device__ __forceinline__ const uint8_t* canon_body_ptr(const QpArgs& A, uint32_t i, const EmailMeta* M) {
-  const uint64_t r0 = A.b.raw_off[i];
-  const uint32_t raw_len = (uint32_t)(A.b.raw_off[i + 1] - r0);
-  if (M->body_src_is_raw) return A.b.raw + r0 + M->body_off;
-  if (M->reuse) return region_b(A.scratch_v, A.scratch_v_off, i, raw_len);
-  return region_b(A.b.scratch, A.b.scratch_off, i, raw_len);
-}
-
-__global__ __launch_bounds__(64) void qp_kernel(QpArgs A) {
-  const uint32_t i = blockIdx.x;
-  if (i >= A.b.n) return;
-  const EmailMeta* M = A.b.meta + i;
-  if (M->state != ST_CAND) return;
+// remove_quoted_printable_soft_breaks by the calling wave: n bytes of canonical body at src -> dst (zero padded to n)
+__device__ __forceinline__ void qp_wave(const uint8_t* src, uint32_t n, uint8_t* dst) {
   const int lane = lane_id();
-  const uint32_t n = M->hashed_len;
-  const uint8_t* src = canon_body_ptr(A, i, M);
-  uint8_t* dst = A.clean + A.clean_off[i];
   uint32_t o = 0;
   uint32_t carry = 0;            // how many leading bytes of this chunk belong to a "=\r\n" begun in the previous one
   for (uint32_t base = 0; base < n; base += 64) {
@@ -78,6 +63,53 @@ __global__ __launch_bounds__(64) void qp_kernel(QpArgs A) {
     o += (uint32_t)__builtin_popcountll(Km);
   }
   for (uint32_t l = o + lane; l < n; l += 64) dst[l] = 0;     // email.rs:79: pad back to the original length
+}
+
+// The preparation of the regex stage as ONE launch, one e-mail per wave (it was three: the front end in mode 1, the body
+// canonicaliser, the QP filter — each a dispatch that queues behind the other batches in flight):
+//   canonicalize_signed_email (core/src/circuits.rs:34-35) — for nearly every e-mail the first DKIM-Signature header IS the
+//   verified one and the verify pass's preimage and canonical body are reused: such a wave never stages or parses anything,
+//   it copies a dozen words of the verify pass's EmailMeta; otherwise the front end runs again for the first signature
+//   (mode 1) and the body is canonicalised;
+//   remove_quoted_printable_soft_breaks (circuits.rs:37) — only when somebody will read the cleaned body: a batch without
+//   body parts never looks at it (circuits.rs:48-56), so `want_clean` is off unless body parts or a parity buffer ask for it.
+struct PrepArgs { ParseArgs parse; QpArgs qp; uint32_t want_clean; };
+__global__ __launch_bounds__(64, ZKE_PARSE_WAVES) void regex_prep_kernel(PrepArgs A) {
+  __shared__ ParseLds L;
+  const BatchDev& B = A.parse.b;
+  const uint32_t i = blockIdx.x;
+  if (i >= B.n) return;
+  // what parse_email<_, 1> is going to decide, from the verify pass's state (written by earlier launches: plain loads)
+  const EmailMeta* V = B.meta_verify + i;
+  const bool ok = B.results[i].status == ZKE_OK;
+  const bool reuse = ok && (V->first_sig_hdr == V->cand_hdr || (A.parse.strict & ZKE_STRICT_CANON_VERIFIED));
+  parse_email<true, 1>(A.parse, i, L);
+  if (!ok) return;
+  const uint64_t r0 = B.raw_off[i];
+  const uint32_t raw_len = (uint32_t)(B.raw_off[i + 1] - r0);
+  uint8_t* dst = A.qp.clean + A.qp.clean_off[i];
+  if (reuse) {
+    if (!A.want_clean) return;
+    const uint32_t n = (A.parse.strict & ZKE_STRICT_CANON_IGNORES_L) ? V->canon_full_len : V->hashed_len;
+    const uint8_t* src = V->body_src_is_raw ? B.raw + r0 + V->body_off : region_b(A.qp.scratch_v, A.qp.scratch_v_off, i, raw_len);
+    qp_wave(src, n, dst);
+    return;
+  }
+  // The rare e-mail whose first DKIM-Signature is not the verified one.  The wave reads back what its lane 0 stored to
+  // EmailMeta, and further down the canonical body it wrote: past this CU's L1 (agent-scope fences: an L2 write-back /
+  // invalidate on this chip, affordable on a path this rare)
+  EmailMeta* M = B.meta + i;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  auto ld = [](const uint32_t* q) { return uni(__hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); };
+  if (ld(&M->state) != ST_CAND) return;
+  canon_body_wave(B, i, 1, ld(&M->flags), ld(&M->body_off), ld(&M->body_len), ((uint64_t)ld(&M->len_tag_hi) << 32) | ld(&M->len_tag_lo),
+                  L.stage, (A.parse.strict & ZKE_STRICT_CANON_IGNORES_L) != 0, false);
+  if (!A.want_clean) return;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  const uint8_t* src = ld(&M->body_src_is_raw) ? B.raw + r0 + ld(&M->body_off) : region_b(B.scratch, B.scratch_off, i, raw_len);
+  qp_wave(src, ld(&M->hashed_len), dst);
 }
 
 // ---- dense DFA search ------------------------------------------------------------------------
@@ -362,16 +394,69 @@ __device__ __forceinline__ void dfa_haystack(const DfaArgs& A, uint32_t i, const
   else { hay = (M->reuse ? A.scratch_v + A.scratch_v_off[i] : A.b.scratch + A.b.scratch_off[i]); hlen = M->preimage_len; }
 }
 
+// ---- the verdict of the regex stage, folded part by part ------------------------------------------------------------
+// process_regex_parts walks the parts in order and stops at the first that fails (core/src/regex.rs:35-46; header parts, then
+// body parts: circuits.rs:43-56).  The fold below is that walk with the record as its state: `decided` = a part has failed
+// (or the e-mail never got this far), later parts no longer touch the record.
+struct RegexFold { bool decided; };
+__device__ __forceinline__ RegexFold regex_fold_begin(zke_result* R, const EmailMeta* M) {
+  if (R->status != ZKE_OK) return RegexFold{true};                 // verify_email already panicked (circuits.rs:32)
+  if (M->state == ST_FINAL) { R->status = M->status; R->detail = M->detail; return RegexFold{true}; }   // circuits.rs:35
+  return RegexFold{false};
+}
+__device__ __forceinline__ void regex_fold_part(RegexFold& F, zke_result* R, uint32_t p, uint32_t n_header_parts, const PartRes& pr) {
+  if (F.decided) return;
+  R->regex_part = p; R->match_count = 0; R->match_start = 0; R->match_end = 0;
+  if (pr.code == PART_DECODE_FAIL) { R->status = ZKE_DFA_DECODE_FAIL; R->detail = pr.count; F.decided = true; return; }   // regex.rs:32-33; detail: the blob section
+  R->match_count = pr.count; R->match_start = pr.start; R->match_end = pr.end;
+  if (pr.code) {
+    R->status = pr.code == ZKE_D_U_CAPTURE_FFFD ? ZKE_UNSUPPORTED : (p < n_header_parts ? ZKE_HEADER_REGEX_FAIL : ZKE_BODY_REGEX_FAIL);
+    R->detail = pr.code;
+    F.decided = true;
+  }
+}
+
+// Parts [part0, part0 + np) of a batch in ONE launch: blockIdx.y picks the part (each block stages that part's tables), so
+// the parts' walks overlap instead of queueing behind each other — these launches are a few dozen to a few hundred blocks on
+// a 256-CU chip, their duration is one walk's latency.  `finalize` (only with np == 1): this is the regex stage's last
+// launch and it holds the last part alone — its threads fold the results of the parts before part0 (written by earlier
+// launches) and then their own into the records, and the stage needs no verdict launch.
+constexpr uint32_t DFA_MULTI_MAX = 8;
+struct DfaMultiArgs {
+  DfaArgs common;                         // part / re / is_body / lds_tables / idle are filled per part from the arrays
+  uint32_t part0, np;                     // this launch's parts
+  uint32_t n_header_parts;
+  uint32_t finalize;
+  const RegexDev* re[DFA_MULTI_MAX];
+  uint32_t lds_tables[DFA_MULTI_MAX];
+  uint32_t idle[DFA_MULTI_MAX];
+  uint32_t detail[DFA_MULTI_MAX];
+};
+__device__ __forceinline__ DfaArgs dfa_part_args(const DfaMultiArgs& MA, uint32_t k) {
+  DfaArgs A = MA.common;
+  A.part = MA.part0 + k;
+  A.re = MA.re[k]; A.lds_tables = MA.lds_tables[k]; A.idle = MA.idle[k]; A.decode_detail = MA.detail[k];
+  A.is_body = A.part >= MA.n_header_parts ? 1u : 0u;
+  return A;
+}
+
 // blockDim = 256; one e-mail per lane.  Dynamic LDS: fwd table | rev table | 4 x 256-byte maps.
-__global__ __launch_bounds__(256) void dfa_kernel(DfaArgs A) {
+__global__ __launch_bounds__(256) void dfa_kernel(DfaMultiArgs MA) {
   extern __shared__ __attribute__((aligned(16))) uint8_t dlds[];
+  const DfaArgs A = dfa_part_args(MA, blockIdx.y);
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   DfaLds F{}, Rv{};
   const bool valid = dfa_stage(A, dlds, F, Rv);
   if (i >= A.b.n) return;
   const EmailMeta* M = A.b.meta + i;
+  zke_result* R = A.b.results + i;
+  RegexFold fold{false};
+  if (MA.finalize) {
+    fold = regex_fold_begin(R, M);
+    for (uint32_t p = 0; p < MA.part0; p++) regex_fold_part(fold, R, p, MA.n_header_parts, A.out[(size_t)i * A.P + p]);
+  }
   PartRes pr{PART_SKIPPED, 0, 0, 0};
-  if (M->state == ST_CAND) {
+  if (M->state == ST_CAND && !fold.decided) {      // (a part behind the first failing one is never looked at: regex.rs:38,45)
     if (!valid) {
       pr.code = PART_DECODE_FAIL; pr.count = A.decode_detail;
     } else {
@@ -381,6 +466,7 @@ __global__ __launch_bounds__(256) void dfa_kernel(DfaArgs A) {
     }
   }
   A.out[(size_t)i * A.P + A.part] = pr;
+  if (MA.finalize) regex_fold_part(fold, R, A.part, MA.n_header_parts, pr);
 }
 
 // One e-mail per WAVE (blockDim = 256: four e-mails share the staged tables).  A DFA walk is a serial chain, but
@@ -389,33 +475,26 @@ __global__ __launch_bounds__(256) void dfa_kernel(DfaArgs A) {
 // — the same code as the lane-per-e-mail kernel, run wave-uniformly — then steps over runs of clean chunks and walks
 // only the chunks around the matches.  4 KB bodies: 64 dependent steps in the parallel pass + a few hundred serial
 // ones instead of ~4 100.
-// All parts of the batch in one launch: blockIdx.y picks the part (each block stages that part's tables), so the
-// parts' walks overlap instead of queueing behind each other.
-constexpr uint32_t DFA_MULTI_MAX = 8;
-struct DfaMultiArgs {
-  DfaArgs common;                         // part / re / is_body / lds_tables / idle are filled per block from the arrays
-  uint32_t part0;                         // index of the first part of this launch
-  uint32_t n_header_parts;
-  const RegexDev* re[DFA_MULTI_MAX];
-  uint32_t lds_tables[DFA_MULTI_MAX];
-  uint32_t idle[DFA_MULTI_MAX];
-  uint32_t detail[DFA_MULTI_MAX];
-};
-
 __global__ __launch_bounds__(256) void dfa_wave_kernel(DfaMultiArgs MA) {
   extern __shared__ __attribute__((aligned(16))) uint8_t dlds[];
-  DfaArgs A = MA.common;
-  A.part = MA.part0 + blockIdx.y;
-  A.re = MA.re[blockIdx.y]; A.lds_tables = MA.lds_tables[blockIdx.y]; A.idle = MA.idle[blockIdx.y]; A.decode_detail = MA.detail[blockIdx.y];
-  A.is_body = A.part >= MA.n_header_parts ? 1u : 0u;
+  const DfaArgs A = dfa_part_args(MA, blockIdx.y);
   const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   DfaLds F{}, Rv{};
   const bool valid = dfa_stage(A, dlds, F, Rv);
   if (i >= A.b.n) return;
   const EmailMeta* M = A.b.meta + i;
+  zke_result* R = A.b.results + i;
+  RegexFold fold{false};                           // (the record is lane 0's business; every lane gets its `decided`)
+  if (MA.finalize) {
+    if (lane == 0) {
+      fold = regex_fold_begin(R, M);
+      for (uint32_t p = 0; p < MA.part0; p++) regex_fold_part(fold, R, p, MA.n_header_parts, A.out[(size_t)i * A.P + p]);
+    }
+    fold.decided = __builtin_amdgcn_readfirstlane((int)fold.decided) != 0;
+  }
   PartRes pr{PART_SKIPPED, 0, 0, 0};
-  if (M->state == ST_CAND) {
+  if (M->state == ST_CAND && !fold.decided) {
     if (!valid) {
       pr.code = PART_DECODE_FAIL; pr.count = A.decode_detail;
     } else {
@@ -450,32 +529,22 @@ __global__ __launch_bounds__(256) void dfa_wave_kernel(DfaMultiArgs MA) {
       pr = dfa_part(A, F, Rv, i, hay, hlen, acc);
     }
   }
-  if (lane == 0) A.out[(size_t)i * A.P + A.part] = pr;
+  if (lane == 0) {
+    A.out[(size_t)i * A.P + A.part] = pr;
+    if (MA.finalize) regex_fold_part(fold, R, A.part, MA.n_header_parts, pr);
+  }
 }
 
-// ---- verdict of the regex stage (thread per e-mail) ------------------------------------------
+// ---- verdict of the regex stage as a launch of its own (when the last DFA launch holds more than one part) ----------------
 struct RegexFinArgs { BatchDev b; const PartRes* parts; uint32_t n_header_parts, n_body_parts; };
 
 __global__ void regex_finalize_kernel(RegexFinArgs A) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= A.b.n) return;
   zke_result* R = A.b.results + i;
-  if (R->status != ZKE_OK) return;                 // verify_email already panicked (circuits.rs:32)
-  const EmailMeta* M = A.b.meta + i;               // canonicalize pass
-  if (M->state == ST_FINAL) { R->status = M->status; R->detail = M->detail; return; }   // circuits.rs:35
+  RegexFold fold = regex_fold_begin(R, A.b.meta + i);
   const uint32_t P = A.n_header_parts + A.n_body_parts;
-  for (uint32_t p = 0; p < P; p++) {
-    const PartRes pr = A.parts[(size_t)i * P + p];
-    R->regex_part = p; R->match_count = 0; R->match_start = 0; R->match_end = 0;
-    if (pr.code == PART_DECODE_FAIL) { R->status = ZKE_DFA_DECODE_FAIL; R->detail = pr.count; return; }   // regex.rs:32-33; detail: the blob section
-    R->match_count = pr.count; R->match_start = pr.start; R->match_end = pr.end;
-    if (pr.code) {
-      R->status = pr.code == ZKE_D_U_CAPTURE_FFFD ? ZKE_UNSUPPORTED
-                                                  : (p < A.n_header_parts ? ZKE_HEADER_REGEX_FAIL : ZKE_BODY_REGEX_FAIL);
-      R->detail = pr.code;
-      return;
-    }
-  }
+  for (uint32_t p = 0; p < P; p++) regex_fold_part(fold, R, p, A.n_header_parts, A.parts[(size_t)i * P + p]);
 }
 
 }  // namespace zke
