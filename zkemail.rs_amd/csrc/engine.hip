@@ -80,6 +80,8 @@ struct Slot {
   zke_timings last{};                  // ... and what they said, once read
   DevBuf meta, rsa_jobs, sha_jobs, sha_order, rsa_ok, em_dbg, scratch_off, scratch, clean, meta2, scratch2, parts;
   DevBuf pending;  // device counters: e-mails that need another signature round, the wave-routine job list's length
+  uint32_t* wave_feedback = nullptr;   // pinned host word the verdict launch leaves that length in: the slot's next batch sizes the
+                                       // one-signature-per-wave role of its hash / modexp launch by it (0xFFFFFFFF: nothing known yet)
   // host entry: the packed input image (pinned + HBM), the records (HBM + pinned), the batch not yet delivered
   PinnedBuf h_image, h_results;
   DevBuf d_image, d_results;
@@ -163,6 +165,8 @@ Slot* new_slot(zke_engine* e) {
             hipEventCreateWithFlags(&w->done, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&w->host_done, hipEventDisableTiming) == hipSuccess;
   for (auto& ev : w->ev) ok = ok && hipEventCreate(&ev) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&w->wave_feedback, 64, hipHostMallocMapped) == hipSuccess;
+  if (ok) *w->wave_feedback = 0xFFFFFFFFu;
   if (!ok) { g_err = "slot stream / event creation"; delete w; return nullptr; }
   for (auto* b : w->all) b->generation = &w->generation;
   return w;
@@ -176,6 +180,7 @@ void free_slot(Slot* w) {
   for (auto& ev : w->ev) if (ev) (void)hipEventDestroy(ev);
   if (w->done) (void)hipEventDestroy(w->done);
   if (w->host_done) (void)hipEventDestroy(w->host_done);
+  if (w->wave_feedback) (void)hipHostFree(w->wave_feedback);
   if (w->stream) (void)hipStreamDestroy(w->stream);
   delete w;
 }
@@ -204,19 +209,33 @@ int launch_stage(zke_engine* e, const StageArgs& A, hipStream_t s) {
 // The hash / modexp stage of a batch (fused.hip.h): SHA-256 of the 4 * n_pad messages and the RSA operation of the n jobs.
 // Launches of up to SHA_PAIR_MAX_GROUPS SHA-256 groups (every BASELINE-sized batch) are ONE kernel; beyond that the chip
 // is full of SHA-256 waves anyway: sha256_batch_kernel first, then the RSA roles as a launch of their own.
+// The one-signature-per-wave role walks the front end's job list: the e-mails whose key is not cached yet (or that the
+// lane-group routines do not take).  Once a stream of batches has its keys cached the list is empty, and every workgroup of the
+// role still has to be given LDS and registers on a full chip just to look and leave (57 % of the launch's waves did nothing
+// else).  So the role is sized by what the slot's PREVIOUS batch needed — its verdict launch leaves the list's length in a
+// pinned word, no synchronisation, one batch stale —: 8 workgroups when that was empty, up to 128 (256 waves: a batch of 1 024
+// uncached keys takes four rounds of them) when every key was new.  The walkers loop, so a wrong guess costs time, never work.
 #ifndef ZKE_WAVE_ROLE_MAX_GROUPS
-#define ZKE_WAVE_ROLE_MAX_GROUPS 128     // 256 waves walk the job list: a batch of 1 024 uncached keys takes four rounds of them
+#define ZKE_WAVE_ROLE_MAX_GROUPS 128
+#endif
+#ifndef ZKE_WAVE_ROLE_MIN_GROUPS
+#define ZKE_WAVE_ROLE_MIN_GROUPS 8
 #endif
 int launch_hash_modexp(zke_engine* e, const ShaJob* sha, uint32_t n_sha, const RsaJob* rsa, uint32_t n, EmailMeta* meta,
                        uint8_t* em_out, uint32_t route_mask, const uint32_t* wave_count, const uint32_t* wave_list, const uint32_t* order,
-                       hipStream_t s) {
+                       uint32_t last_wave_jobs, hipStream_t s) {
   StageArgs A{};
   A.order = order; A.n_pad = n_sha / 4;
   A.sha = sha; A.n_sha = n_sha; A.rsa = rsa; A.n = n; A.meta = meta;
   A.cache = e->key_cache.as<KeyCacheEntry>();
   A.em_out = em_out;
   A.wave_count = wave_count; A.wave_list = wave_list;
-  A.g_wave = wave_list ? std::min<uint32_t>((n + 1) / 2, ZKE_WAVE_ROLE_MAX_GROUPS) : (n + 1) / 2;
+  A.g_wave = (n + 1) / 2;
+  if (wave_list) {
+    const uint32_t want = last_wave_jobs == 0xFFFFFFFFu ? ZKE_WAVE_ROLE_MAX_GROUPS
+                                                        : std::max<uint32_t>(ZKE_WAVE_ROLE_MIN_GROUPS, (std::min<uint32_t>(last_wave_jobs, n) + 1) / 2);
+    A.g_wave = std::min<uint32_t>(A.g_wave, std::min<uint32_t>(want, ZKE_WAVE_ROLE_MAX_GROUPS));
+  }
   A.g_quad = (route_mask & 1u) ? (n + 31) / 32 : 0;
   A.g_oct = (route_mask & 2u) ? (n + 15) / 16 : 0;
   A.debug_skip_rsa = e->debug_skip_rsa;

@@ -118,12 +118,13 @@ int run_device_pipeline(zke_engine* e, Slot& w, const zke_batch* in, uint64_t ra
     tm.mark(MK_FRONT);
     // hash / modexp stage: the four SHA-256 jobs and the RSA operation of every e-mail, one launch (fused.hip.h)
     if (!(e->debug_skip_launch & 1) &&
-        (r = launch_hash_modexp(e, B.sha, 4 * n_pad, B.rsa, n, B.meta, want_em ? w.em_dbg.as<uint8_t>() : nullptr, route_mask, wave_count, wave_list, B.order, s)))
+        (r = launch_hash_modexp(e, B.sha, 4 * n_pad, B.rsa, n, B.meta, want_em ? w.em_dbg.as<uint8_t>() : nullptr, route_mask, wave_count, wave_list, B.order,
+                                __atomic_load_n(w.wave_feedback, __ATOMIC_RELAXED), s)))
       return r;
     tm.mark(MK_HASH);
     // Ed25519 stage + verdicts (verdict.hip.h): bh compare, EM digest against the header hash, status / detail, pending counter
     EdVerdictArgs va{FinArgs{B, round, rounds, w.pending.as<uint32_t>(), e->debug_skip_rsa}, e->debug_skip_ed, wave_count,
-                     e->key_cache.as<KeyCacheEntry>(), want_em ? w.em_dbg.as<uint8_t>() : nullptr, e->strict, now};
+                     e->key_cache.as<KeyCacheEntry>(), want_em ? w.em_dbg.as<uint8_t>() : nullptr, e->strict, now, w.wave_feedback};
     if (!(e->debug_skip_launch & 2)) hipLaunchKernelGGL(ed_verdict_kernel, dim3((n + VERDICT_EMAILS_PER_WAVE - 1) / VERDICT_EMAILS_PER_WAVE), dim3(64), 0, s, va);
     tm.mark(MK_VERDICT);
   }

@@ -20,6 +20,8 @@ struct EdVerdictArgs {
   uint8_t* em_out;           // parity intermediates (nullptr in production)
   uint32_t strict;           // ZKE_STRICT_* and the x= clock, for the front end of later signature rounds
   uint64_t now;
+  uint32_t* wave_feedback;   // pinned host word of the slot: how long the wave-routine job list of this batch was (sizes the next
+                             // batch's walkers: engine.hip, launch_hash_modexp); nullptr: nobody listens
 };
 
 // SHA-256 / SHA-1 of one message by ONE LANE (later signature rounds only: two messages per e-mail, a rare path; the
@@ -104,7 +106,10 @@ __global__ __launch_bounds__(64, ZKE_VERDICT_WAVES) void ed_verdict_kernel(EdVer
   const BatchDev& B = A.fin.b;
   const int lane = threadIdx.x & 63;
   const uint32_t base = blockIdx.x * VERDICT_EMAILS_PER_WAVE;
-  if (blockIdx.x == 0 && lane == 0 && A.wave_count) *A.wave_count = 0;
+  if (blockIdx.x == 0 && lane == 0 && A.wave_count) {
+    if (A.wave_feedback) __hip_atomic_store(A.wave_feedback, *A.wave_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    *A.wave_count = 0;
+  }
   if (blockIdx.x == 0 && B.order)              // the hash stage has consumed the length buckets: counters back to zero for the slot's next batch
     for (uint32_t k = 0; k < 2; k++)
       for (uint32_t c = (uint32_t)lane; c < SHA_CLASSES; c += 64) B.order[sha_order_cnt(k) + c] = 0;
