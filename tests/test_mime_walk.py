@@ -65,6 +65,18 @@ CASES = [
     ("message_rfc822_is_a_leaf", H + b"--xx\r\nContent-Type: message/rfc822\r\n\r\nContent-Type: multipart/mixed; boundary=yy\r\n\r\n--yy\r\n bad\r\n--yy--\r\n--xx--\r\n", (0, 0)),
     ("leaf_with_encoded_word", H + b"--xx\r\nContent-Type: application/pdf; name=\"=?UTF-8?B?w6k=?=\"\r\n\r\n--xx--\r\n", (0, 0)),
     ("leaf_with_8bit_after_first_token", H + b"--xx\r\nContent-Type: text/plain; name=\"\xc3\xa9\"\r\n\r\n--xx--\r\n", (0, 0)),
+    # Hand-derived from the rules of mailparse 0.15.0's parse_mail_recursive AS RECALLED (the crate is not vendored and could
+    # not be read here: parity unpinned against mailparse itself — DESIGN.md §4).  The walk: find_from(body, "--" + boundary)
+    # for the first delimiter, then for each part the next delimiter line; a part whose closing delimiter is missing is not
+    # parsed (`else { break }`); "--" right behind a delimiter ends the walk; a plain `boundary` parameter wins over its
+    # RFC 2231 spellings (`boundary*`), whichever comes first.
+    ("no_closing_boundary_at_all", H + b"--xx\r\n bad\r\n", (0, 0)),
+    ("no_closing_boundary_after_a_good_part", H + b"--xx\r\nA: b\r\n\r\nok\r\n--xx\r\n bad", (0, 0)),
+    ("boundary_at_offset_0_of_a_part_body", H + b"--xx\r\nA: b\r\n\r\n--xx\r\nC: d\r\n\r\nx\r\n--xx--\r\n", (0, 0)),
+    ("boundary_at_offset_0_of_a_part_body_then_a_bad_part", H + b"--xx\r\nA: b\r\n\r\n--xx\r\n bad\r\n--xx--\r\n", (A.ZKE_PARSE_FAIL, A.D_SUBPART_LEADING_SPACE)),
+    ("boundary_at_offset_0_of_the_message_body", b"Content-Type: multipart/mixed; boundary=xx\r\n\r\n--xx\r\n bad\r\n--xx--\r\n", (A.ZKE_PARSE_FAIL, A.D_SUBPART_LEADING_SPACE)),
+    ("plain_boundary_wins_over_boundary_star_behind_it", b"Content-Type: multipart/mixed; boundary=xx; boundary*=us-ascii\'\'yy\r\n\r\n--xx\r\n bad\r\n--xx--\r\n", (A.ZKE_PARSE_FAIL, A.D_SUBPART_LEADING_SPACE)),
+    ("plain_boundary_wins_and_the_star_value_is_never_used", b"Content-Type: multipart/mixed; boundary*=us-ascii\'\'yy; boundary=xx\r\n\r\n--yy\r\n bad\r\n--yy--\r\n", (0, 0)),
     # carve-outs: reported, never guessed
     ("u_encoded_word_in_first_token", b"Content-Type: =?utf-8?q?multipart/mixed?=; boundary=xx\r\n\r\n--xx\r\n bad\r\n--xx--\r\n", (A.ZKE_UNSUPPORTED, A.D_U_MIME_CTYPE)),
     ("u_encoded_word_in_multipart", b"Content-Type: multipart/mixed; boundary=xx; x=\"=?utf-8?q?a?=\"\r\n\r\n--xx\r\n bad\r\n--xx--\r\n", (A.ZKE_UNSUPPORTED, A.D_U_MIME_CTYPE)),
