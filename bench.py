@@ -588,30 +588,53 @@ def end_to_end_leg(torch, dev, eng, packed, n, S, totals, wl, seconds=2.0):
     from zkemail_rs_amd import _abi as A
     import ctypes as C
     lib, h = eng.lib, eng.h
+    import threading
     outs = [np.zeros(n, dtype=A.RESULT_DTYPE) for _ in range(S)]
-    tickets = [None] * S
     eng.reserve_host(n, totals[0] + totals[1] + totals[2] + int(packed.cap_str_off[-1]) + 4 * (len(packed.cap_off) + len(packed.cap_str_off)))
 
-    def run(steps):
-        t0 = time.perf_counter()
-        for i in range(steps):
-            k = i % S
-            if tickets[k] is not None:
-                assert lib.zke_batch_wait(h, tickets[k]) == 0
-            t = C.c_uint64()
-            rc = lib.zke_verify_batch_async(h, C.byref(packed.c), outs[k].ctypes.data, C.byref(t))
-            assert rc == 0, lib.zke_last_error(h)
-            tickets[k] = t.value
-        for k in range(S):
-            if tickets[k] is not None:
-                assert lib.zke_batch_wait(h, tickets[k]) == 0
-                tickets[k] = None
-        return time.perf_counter() - t0
+    def submitter(my_outs, steps, err):
+        """One submitting thread: its own ring of record arrays, a batch waited for when its array comes round again (the entry
+        points are re-entrant: several of these run on the one engine; ctypes releases the GIL inside the calls)."""
+        try:
+            ring = [None] * len(my_outs)
+            for i in range(steps):
+                k = i % len(ring)
+                if ring[k] is not None:
+                    assert lib.zke_batch_wait(h, ring[k]) == 0
+                t = C.c_uint64()
+                rc = lib.zke_verify_batch_async(h, C.byref(packed.c), my_outs[k].ctypes.data, C.byref(t))
+                assert rc == 0, lib.zke_last_error(h)
+                ring[k] = t.value
+            for t in ring:
+                if t is not None:
+                    assert lib.zke_batch_wait(h, t) == 0
+        except Exception as ex:          # noqa: BLE001
+            err.append(repr(ex))
 
-    run(2 * S)                                            # every slot's staging has been used once
-    probe = run(2 * S) / (2 * S)
-    steps = int(max(3 * S, min(20000, seconds / max(probe, 1e-6))))
-    dt = run(steps)
+    def run(steps, threads):
+        err = []
+        per = max(1, S // threads)
+        ths = [threading.Thread(target=submitter, args=(outs[j * per:(j + 1) * per], steps // threads, err)) for j in range(threads)]
+        t0 = time.perf_counter()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        assert not err, err[:2]
+        return time.perf_counter() - t0, (steps // threads) * threads
+
+    run(2 * S, 1)                                         # every slot's staging has been used once
+    # ONE submitting thread, as a simple caller has (two were measured: 5.1-5.2 M e-mails/s against 5.1-5.6 M — the packing copies are
+    # bound by host memory, not by the submitting thread)
+    best = None
+    for threads in (1,):
+        d, k = run(4 * S, threads)
+        d, k = run(max(6 * S, min(20000, int(seconds / 2 / max(d / k, 1e-6)))), threads)
+        if best is None or k / d > best[1] / best[0]:
+            best = (d, k, threads)
+        if threads == 1:
+            one = (d, k)
+    dt, steps, submit_threads = best
     expect_ok = np.array([it.get("corrupt") is None for it in wl.inter])
     for o in outs:
         assert ((o["status"] == 0) == expect_ok).all(), "end-to-end leg: records differ from what the signer expects"
@@ -632,7 +655,8 @@ def end_to_end_leg(torch, dev, eng, packed, n, S, totals, wl, seconds=2.0):
     rate = steps * n / dt
     h2d = steps * bytes_in / dt / 1e9
     return {"value": round(rate, 1), "unit": "emails/s", "entry": "zke_verify_batch_async + zke_batch_wait, pageable host memory in, records out",
-            "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4), "batches_in_flight": S, "host_threads": int(eng.options.host_threads),
+            "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4), "batches_in_flight": S, "host_threads": int(eng.options.host_threads) or 4,
+            "submit_threads": submit_threads, "value_one_submit_thread": round(one[1] * n / one[0], 1),
             "bytes_per_email_h2d": round(bytes_in / n, 1), "bytes_per_email_d2h": 192,
             "h2d_GBps": round(h2d, 2), "pcie_h2d_GBps_pinned_link": round(link, 2), "frac_of_pcie": round(h2d / link, 4),
             "emails_per_s_pcie_allows": round(link * 1e9 / (bytes_in / n), 1)}

@@ -383,6 +383,36 @@ int zke_verify_email_with_regex(zke_engine* e, const uint8_t* raw, size_t raw_le
                                 const zke_regex_part* body_parts, uint32_t n_body_parts,
                                 zke_result* out);
 
+/* ---- serialised inputs -------------------------------------------------------------------------
+ * The byte streams the zkVM hosts already produce for Email / EmailWithRegex (the derives at core/src/structs.rs:1-6): borsh
+ * under the reference's `risc0` feature (u32 lengths), bincode 1.x default options over serde under `sp1` (u64 lengths).  Read
+ * in place — every pointer of a zke_wire_email points into the caller's buffer, which must outlive the document. */
+#define ZKE_WIRE_BORSH   0u
+#define ZKE_WIRE_BINCODE 1u
+typedef struct zke_wire_doc zke_wire_doc;
+typedef struct zke_wire_email {                 /* Email (structs.rs:49-54) + RegexInfo (structs.rs:32-35) as the entry points take them */
+  const uint8_t* raw; size_t raw_len;           /* Email.raw_email */
+  const char* from_domain; size_t domain_len;   /* Email.from_domain (UTF-8, validated) */
+  const uint8_t* key; size_t key_len;           /* Email.public_key.key */
+  uint32_t key_type;                            /* ZKE_KEY_* of Email.public_key.key_type */
+  uint32_t n_external_inputs;                   /* Email.external_inputs.len(); zke_wire_external_input reads one */
+  uint32_t external_input_null;                 /* 1: some ExternalInput.value is None (circuits.rs:24) */
+  uint32_t has_header_parts, has_body_parts;    /* Option tags of RegexInfo.header_parts / body_parts */
+  uint32_t n_header_parts, n_body_parts;
+  const zke_regex_part* header_parts;           /* [n_header_parts]; captures: None -> n_captures 0 */
+  const zke_regex_part* body_parts;
+} zke_wire_email;
+/* Decode ONE record at bytes[0, len): Email (with_regex == 0) or EmailWithRegex.  *consumed = its size (records may follow
+ * each other in a stream).  ZKE_E_ARG with a message (zke_last_error(NULL)) for a truncated or malformed stream. */
+int zke_wire_decode(uint32_t format, const uint8_t* bytes, size_t len, uint32_t with_regex, zke_wire_doc** out, size_t* consumed);
+void zke_wire_free(zke_wire_doc* d);
+int zke_wire_view(const zke_wire_doc* d, zke_wire_email* out);
+int zke_wire_external_input(const zke_wire_doc* d, uint32_t i, const uint8_t** name, size_t* name_len,
+                            const uint8_t** value, size_t* value_len, uint32_t* is_null);
+/* verify_email / verify_email_with_regex of one serialised record: decode + zke_verify_email[_with_regex].  The record must
+ * fill bytes[0, len) exactly. */
+int zke_verify_wire(zke_engine* e, uint32_t format, const uint8_t* bytes, size_t len, uint32_t with_regex, zke_result* out);
+
 /* Building blocks, exported for parity tests and micro-benchmarks.  Host pointers. */
 /* n messages msg_blob[off[i]..off[i+1]) -> digests[32*i..]           (core/src/crypto.rs:3-7) */
 int zke_sha256_batch(zke_engine* e, const uint8_t* msg_blob, const uint64_t* off,

@@ -155,6 +155,17 @@ STRICT_FLAGS = ("enforce_expiry_x", "canon_takes_verified_signature", "canon_ign
                 "b_removes_own_span_only")          # zke_options' strictness flags, in ZKE_STRICT_* bit order
 
 
+class zke_wire_email(C.Structure):
+    """View of one decoded borsh / bincode record (zke_wire_decode): pointers into the caller's buffer."""
+    _fields_ = [
+        ("raw", C.c_void_p), ("raw_len", C.c_size_t), ("from_domain", C.c_void_p), ("domain_len", C.c_size_t),
+        ("key", C.c_void_p), ("key_len", C.c_size_t), ("key_type", C.c_uint32), ("n_external_inputs", C.c_uint32),
+        ("external_input_null", C.c_uint32), ("has_header_parts", C.c_uint32), ("has_body_parts", C.c_uint32),
+        ("n_header_parts", C.c_uint32), ("n_body_parts", C.c_uint32),
+        ("header_parts", C.POINTER(zke_regex_part)), ("body_parts", C.POINTER(zke_regex_part)),
+    ]
+
+
 class zke_options(C.Structure):
     """ABI 0.3: named fields; a zero-filled struct is the default configuration (device 0)."""
     _fields_ = [

@@ -265,6 +265,7 @@ int set_kernel_attrs(zke_engine* e) {
 }  // namespace
 
 #include "pipeline.hip.h"
+#include "wire.hip.h"
 
 extern "C" {
 

@@ -87,6 +87,16 @@ def load_library(path: Optional[str] = None):
     lib.zke_engine_reserve.restype = C.c_int
     lib.zke_engine_reserve_host.argtypes = [vp, C.c_uint32, C.c_uint64]
     lib.zke_engine_reserve_host.restype = C.c_int
+    lib.zke_wire_decode.argtypes = [C.c_uint32, vp, C.c_size_t, C.c_uint32, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    lib.zke_wire_decode.restype = C.c_int
+    lib.zke_wire_free.argtypes = [vp]
+    lib.zke_wire_free.restype = None
+    lib.zke_wire_view.argtypes = [vp, C.POINTER(A.zke_wire_email)]
+    lib.zke_wire_view.restype = C.c_int
+    lib.zke_wire_external_input.argtypes = [vp, C.c_uint32, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp), C.POINTER(C.c_size_t), u32p]
+    lib.zke_wire_external_input.restype = C.c_int
+    lib.zke_verify_wire.argtypes = [vp, C.c_uint32, vp, C.c_size_t, C.c_uint32, vp]
+    lib.zke_verify_wire.restype = C.c_int
     lib.zke_get_slot_timings.argtypes = [vp, C.c_uint32, C.POINTER(A.zke_timings)]
     lib.zke_get_slot_timings.restype = C.c_int
     lib.zke_sha256_batch.argtypes = [vp, vp, vp, C.c_uint32, vp]
@@ -115,7 +125,8 @@ EXPORTED_SYMBOLS = [
     "zke_sha256_batch", "zke_sha256_batch_device", "zke_rsa_modexp_batch", "zke_version", "zke_device_available",
     "zke_ed25519_verify_batch", "zke_engine_reserve", "zke_get_slot_timings", "zke_verify_email_with_regex",
     "zke_abi_encode", "zke_engine_join", "zke_verify_batch_async", "zke_batch_wait", "zke_dfa_status", "zke_dfa_unregister",
-    "zke_process_init", "zke_abi_version", "zke_engine_reserve_host",
+    "zke_process_init", "zke_abi_version", "zke_engine_reserve_host", "zke_wire_decode", "zke_wire_free", "zke_wire_view",
+    "zke_wire_external_input", "zke_verify_wire",
 ]
 
 
@@ -238,6 +249,14 @@ class Engine:
         t = A.zke_timings()
         self._check(self.lib.zke_get_timings(self.h, C.byref(t)), "zke_get_timings")
         return {k: getattr(t, k) for k, _ in A.zke_timings._fields_}
+
+    def verify_wire(self, data: bytes, fmt: str = "borsh", with_regex: bool = False) -> np.ndarray:
+        """zke_verify_wire: one borsh / bincode serialised Email or EmailWithRegex (core/src/structs.rs:1-6) -> its record."""
+        out = np.zeros(1, dtype=A.RESULT_DTYPE)
+        buf = np.frombuffer(bytes(data) or b"\0", np.uint8)
+        self._check(self.lib.zke_verify_wire(self.h, {"borsh": 0, "bincode": 1}[fmt], buf.ctypes.data, len(data), 1 if with_regex else 0,
+                                             out.ctypes.data), "zke_verify_wire")
+        return out[0]
 
     # ---- building blocks
     def sha256_batch(self, msgs: Sequence[bytes]) -> np.ndarray:
