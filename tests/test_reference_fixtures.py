@@ -151,4 +151,7 @@ def test_engine_equals_oracle_on_the_manifest(engine, oracle):
     for f in A.RESULT_DTYPE.names:
         if f != "reserved":
             assert (np.asarray(got[f]) == np.asarray(exp[f])).all(), f
-    assert (d1.canon_header == d2.canon_header).all() and (d1.canon_body == d2.canon_body).all()
+    # (an Ed25519 key that is no curve point is found out by the verdict launch, after the front end has canonicalised: the
+    # intermediates of such an e-mail exist on the device and not in the oracle; its record is the oracle's)
+    rows = np.asarray(got["status"]) != A.ZKE_KEY_DECODE_FAIL
+    assert (d1.canon_header[rows] == d2.canon_header[rows]).all() and (d1.canon_body[rows] == d2.canon_body[rows]).all()
