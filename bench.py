@@ -258,23 +258,11 @@ def main():
     base_ptr = results_all.data_ptr()
     counter = [0]
 
-    # experiment knobs (not the measured configuration): caller-provided torch streams instead of the slots' own;
-    # S engines with one slot each instead of one engine with S slots
-    x_torch_streams = os.environ.get("ZKE_BENCH_TORCH_STREAMS") == "1"
-    x_multi_engine = os.environ.get("ZKE_BENCH_MULTI_ENGINE") == "1"
-    tstreams = [torch.cuda.Stream(device=dev) for _ in range(S)] if x_torch_streams else None
-    xengines = None
-    if x_multi_engine:
-        xengines = [z.Engine(device=local_rank) for _ in range(S)]
-        for xe in xengines:
-            xe.reserve(n, totals[0], 1, P)
-
     def step():
         # slot i % S (the engine takes its slots round-robin) on that slot's own stream; record slice i % n_slices
         i = counter[0]
         counter[0] += 1
-        st = tstreams[i % S].cuda_stream if tstreams else 0
-        (xengines[i % S] if xengines else eng).verify_batch_device(cb, totals[0], totals[1], totals[2], base_ptr + (i % n_slices) * rec_bytes, st)
+        eng.verify_batch_device(cb, totals[0], totals[1], totals[2], base_ptr + (i % n_slices) * rec_bytes, 0)
 
     def fence():
         # torch.cuda.synchronize() is a device-wide wait: it covers the engine's slot streams too (eng.sync() would add
@@ -310,22 +298,14 @@ def main():
     for _ in range(args.steps):
         step()
     t_submitted = time.perf_counter() - t0            # the host side of the timed region: K submissions
-    tail = [] if os.environ.get("ZKE_BENCH_TAIL_TIMES") == "1" else None      # diagnosis: where the end of the region goes
     if use_dist:
         # The exchange is enqueued while the batches still run: zke_engine_join orders torch's stream behind every batch in
         # flight on the device, the host does not wait — its ~0.09 ms for the two copies and the all-gather call hide behind
         # the drain instead of following it.  The closing fence waits for everything.
         eng.join(cur_stream)
         exchange()
-        if tail is not None:
-            tail.append(("exchange enqueued", time.perf_counter() - t0))
-            torch.cuda.synchronize()
-            tail.append(("exchange done", time.perf_counter() - t0))
     fence()
     dt = time.perf_counter() - t0
-    if tail is not None:
-        tail.append(("fence done", dt))
-        sys.stderr.write("tail_times_ms " + " | ".join(f"{k} {v * 1e3:.3f}" for k, v in tail) + "\n")
     gc.enable()
     if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -333,7 +313,7 @@ def main():
         dt = float(tmax.item())
 
     # ---- correctness of what was timed (outside the timed region)
-    nocheck = os.environ.get("ZKE_BENCH_NOCHECK") == "1"       # kernel-ablation experiments only: results are not valid
+    nocheck = False
     first_timed = priming + args.warmup
     written = sorted({i % n_slices for i in range(first_timed, counter[0])})
     for sl in ([] if nocheck else sorted(set(written[:S]) | set(written[-2:]))):
