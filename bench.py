@@ -572,6 +572,8 @@ def end_to_end_leg(torch, dev, eng, packed, n, S, totals, wl, seconds=2.0):
     outs = [np.zeros(n, dtype=A.RESULT_DTYPE) for _ in range(S)]
     eng.reserve_host(n, totals[0] + totals[1] + totals[2] + int(packed.cap_str_off[-1]) + 4 * (len(packed.cap_off) + len(packed.cap_str_off)))
 
+    spent = {"submit": 0.0, "wait": 0.0}
+
     def submitter(my_outs, steps, err):
         """One submitting thread: its own ring of record arrays, a batch waited for when its array comes round again (the entry
         points are re-entrant: several of these run on the one engine; ctypes releases the GIL inside the calls)."""
@@ -579,10 +581,14 @@ def end_to_end_leg(torch, dev, eng, packed, n, S, totals, wl, seconds=2.0):
             ring = [None] * len(my_outs)
             for i in range(steps):
                 k = i % len(ring)
+                a = time.perf_counter()
                 if ring[k] is not None:
                     assert lib.zke_batch_wait(h, ring[k]) == 0
+                b = time.perf_counter()
                 t = C.c_uint64()
                 rc = lib.zke_verify_batch_async(h, C.byref(packed.c), my_outs[k].ctypes.data, C.byref(t))
+                spent["wait"] += b - a
+                spent["submit"] += time.perf_counter() - b
                 assert rc == 0, lib.zke_last_error(h)
                 ring[k] = t.value
             for t in ring:
@@ -609,6 +615,7 @@ def end_to_end_leg(torch, dev, eng, packed, n, S, totals, wl, seconds=2.0):
     best = None
     for threads in (1,):
         d, k = run(4 * S, threads)
+        spent["submit"] = spent["wait"] = 0.0
         d, k = run(max(6 * S, min(20000, int(seconds / 2 / max(d / k, 1e-6)))), threads)
         if best is None or k / d > best[1] / best[0]:
             best = (d, k, threads)
@@ -636,7 +643,9 @@ def end_to_end_leg(torch, dev, eng, packed, n, S, totals, wl, seconds=2.0):
     h2d = steps * bytes_in / dt / 1e9
     return {"value": round(rate, 1), "unit": "emails/s", "entry": "zke_verify_batch_async + zke_batch_wait, pageable host memory in, records out",
             "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4), "batches_in_flight": S, "host_threads": int(eng.options.host_threads) or 4,
-            "submit_threads": submit_threads, "value_one_submit_thread": round(one[1] * n / one[0], 1),
+            "submit_threads": submit_threads,
+            "host_us_per_step": {"zke_verify_batch_async (pack into pinned memory + enqueue)": round(spent["submit"] / steps * 1e6, 1),
+                                 "zke_batch_wait (the slot's previous batch: event wait + records to the caller)": round(spent["wait"] / steps * 1e6, 1)},
             "bytes_per_email_h2d": round(bytes_in / n, 1), "bytes_per_email_d2h": 192,
             "h2d_GBps": round(h2d, 2), "pcie_h2d_GBps_pinned_link": round(link, 2), "frac_of_pcie": round(h2d / link, 4),
             "emails_per_s_pcie_allows": round(link * 1e9 / (bytes_in / n), 1)}

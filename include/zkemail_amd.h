@@ -413,6 +413,16 @@ int zke_wire_external_input(const zke_wire_doc* d, uint32_t i, const uint8_t** n
  * fill bytes[0, len) exactly. */
 int zke_verify_wire(zke_engine* e, uint32_t format, const uint8_t* bytes, size_t len, uint32_t with_regex, zke_result* out);
 
+/* ---- one batch over N GPUs ----------------------------------------------------------------------------
+ * Every e-mail is verified in isolation, so ranks take contiguous ranges of a batch balanced by cumulative raw BYTES (not by
+ * count: a ragged batch then loads the ranks evenly) and the data path has no collective; the only exchange is the gather of
+ * the per-e-mail witnesses.  zke_shard_bounds writes bounds[0 .. world]: rank r owns e-mails [bounds[r], bounds[r + 1]) of the
+ * n whose CSR offsets are raw_off[0 .. n]; cut points sit where the cumulative byte count crosses r / world of the total.
+ * Rank r then runs zke_verify_batch_device on its range — the offsets are absolute, so a range is `raw_off + bounds[r]` with
+ * the same blobs — and contributes (bounds[r + 1] - bounds[r]) records.  Pure host code.  (Python:
+ * zkemail_rs_amd.distributed.shard_bounds / ShardedVerifier, the latter with the RCCL all-gather of the witnesses.) */
+int zke_shard_bounds(const uint64_t* raw_off, uint32_t n, uint32_t world, uint32_t* bounds);
+
 /* Building blocks, exported for parity tests and micro-benchmarks.  Host pointers. */
 /* n messages msg_blob[off[i]..off[i+1]) -> digests[32*i..]           (core/src/crypto.rs:3-7) */
 int zke_sha256_batch(zke_engine* e, const uint8_t* msg_blob, const uint64_t* off,

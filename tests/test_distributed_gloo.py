@@ -62,6 +62,22 @@ def test_shard_bounds_properties():
     assert D.shard_bounds([10] * 8, 8) == list(range(9))
 
 
+def test_native_shard_bounds_equal_the_python_ones():
+    """zke_shard_bounds (the C shape of the sharding, include/zkemail_amd.h) against distributed.shard_bounds."""
+    import ctypes as C
+    from zkemail_rs_amd import engine
+    lib = engine.load_library()
+    rng = np.random.default_rng(8)
+    for world in (1, 2, 3, 8):
+        for n in (0, 1, 5, 100, 1000):
+            sizes = [int(x) for x in rng.integers(0, 70000, n)]
+            off = np.concatenate([[12345], 12345 + np.cumsum(np.asarray(sizes, dtype=np.uint64))]).astype(np.uint64)      # offsets need not start at 0
+            out = np.zeros(world + 1, np.uint32)
+            assert lib.zke_shard_bounds(off.ctypes.data, n, world, out.ctypes.data) == 0
+            assert [int(x) for x in out] == D.shard_bounds(sizes, world), (world, n)
+    assert lib.zke_shard_bounds(None, 3, 2, None) == -1 and lib.zke_shard_bounds(None, 0, 0, np.zeros(1, np.uint32).ctypes.data) == -1
+
+
 def test_two_rank_gloo_gather():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     procs = []

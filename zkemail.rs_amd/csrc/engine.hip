@@ -322,6 +322,20 @@ int zke_abi_encode(const uint8_t* from_domain_hash, const uint8_t* public_key_ha
   return w.len == need ? 0 : ZKE_E_ARG;
 }
 
+int zke_shard_bounds(const uint64_t* raw_off, uint32_t n, uint32_t world, uint32_t* bounds) {
+  if (!bounds || world == 0 || (n && !raw_off)) return ZKE_E_ARG;
+  bounds[0] = 0;
+  const uint64_t base = n ? raw_off[0] : 0, total = n ? raw_off[n] - base : 0;
+  uint32_t cut = 0;
+  for (uint32_t r = 1; r < world; r++) {
+    // the first e-mail index whose cumulative byte count reaches total * r / world (compared without a division)
+    while (cut < n && (unsigned __int128)(raw_off[cut] - base) * world < (unsigned __int128)total * r) cut++;
+    bounds[r] = cut;
+  }
+  bounds[world] = n;
+  return 0;
+}
+
 int zke_device_available(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;

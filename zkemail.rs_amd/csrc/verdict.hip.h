@@ -91,7 +91,7 @@ __device__ __noinline__ void next_round(const EdVerdictArgs& A, uint32_t round, 
 #ifndef ZKE_VERDICT_WAVES
 #define ZKE_VERDICT_WAVES 2      // waves per SIMD the verdict launch is compiled for: at 1 it takes 364 registers (256 + 108 AGPRs), which
                                  // keeps the waves of other launches off its SIMD — RSA batches 26.8 M e-mails/s instead of 27.8 M,
-                                 // Ed25519 batches 9.7 M instead of 9.0 M (3 / 4 waves: 7.0 / 6.4 M); tools/r2_ab12.sh
+                                 // Ed25519 batches 9.7 M instead of 9.0 M (3 / 4 waves: 7.0 / 6.4 M); round 2, and again in round 3: 168 / 128 registers with 1.5 / 1.9 KB of scratch change nothing for RSA batches
 #endif
 constexpr uint32_t VERDICT_EMAILS_PER_WAVE = 16;      // a DPP quad per e-mail in the Ed25519 stage
 

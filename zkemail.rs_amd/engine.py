@@ -97,6 +97,8 @@ def load_library(path: Optional[str] = None):
     lib.zke_wire_external_input.restype = C.c_int
     lib.zke_verify_wire.argtypes = [vp, C.c_uint32, vp, C.c_size_t, C.c_uint32, vp]
     lib.zke_verify_wire.restype = C.c_int
+    lib.zke_shard_bounds.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
+    lib.zke_shard_bounds.restype = C.c_int
     lib.zke_get_slot_timings.argtypes = [vp, C.c_uint32, C.POINTER(A.zke_timings)]
     lib.zke_get_slot_timings.restype = C.c_int
     lib.zke_sha256_batch.argtypes = [vp, vp, vp, C.c_uint32, vp]
@@ -126,7 +128,7 @@ EXPORTED_SYMBOLS = [
     "zke_ed25519_verify_batch", "zke_engine_reserve", "zke_get_slot_timings", "zke_verify_email_with_regex",
     "zke_abi_encode", "zke_engine_join", "zke_verify_batch_async", "zke_batch_wait", "zke_dfa_status", "zke_dfa_unregister",
     "zke_process_init", "zke_abi_version", "zke_engine_reserve_host", "zke_wire_decode", "zke_wire_free", "zke_wire_view",
-    "zke_wire_external_input", "zke_verify_wire",
+    "zke_wire_external_input", "zke_verify_wire", "zke_shard_bounds",
 ]
 
 
