@@ -86,6 +86,7 @@ struct Slot {
   PinnedBuf h_image, h_results;
   DevBuf d_image, d_results;
   hipEvent_t host_done = nullptr;      // recorded behind the D2H of the records
+  hipEvent_t h2d_done = nullptr;       // recorded behind the slot's input image on the engine's copy stream
   uint64_t host_gen = 0;               // host batches submitted to this slot
   uint64_t host_retired = 0;           // ... of which this many have been delivered to their caller's `out`
   zke_result* host_out = nullptr;      // where the pending batch's records go
@@ -110,7 +111,15 @@ struct zke_engine {
   std::atomic<uint32_t> ticket{0};  // round-robin cursor of the submission entry points
   std::atomic<uint32_t> last_slot{0};
   std::atomic<bool> timing{false};
+  std::atomic<size_t> host_image_cap{0};   // every slot's pinned staging holds an input image of this many bytes ...
+  std::atomic<uint32_t> host_n_cap{0};     // ... and this many records (grow_host_staging: all slots at once, in a quiet moment)
   hipStream_t stream = nullptr;     // = slots[0]->stream: the building-block entry points
+#ifndef ZKE_COPY_STREAMS
+#define ZKE_COPY_STREAMS 2
+#endif
+  hipStream_t copy_stream[ZKE_COPY_STREAMS]{};   // host batches' input images cross PCIe on these streams, in turn (pipeline.hip.h)
+  std::mutex copy_mu;
+  uint32_t copy_turn = 0;
   std::mutex misc_mu;
   DevBuf misc;                      // building-block entry points
   DevBuf key_cache;                 // KeyCacheEntry[KEY_CACHE_SLOTS]: per-key Montgomery constants, kept across batches, shared by the slots
@@ -163,7 +172,8 @@ Slot* new_slot(zke_engine* e) {
   Slot* w = new Slot();
   bool ok = hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreateWithFlags(&w->done, hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&w->host_done, hipEventDisableTiming) == hipSuccess;
+            hipEventCreateWithFlags(&w->host_done, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&w->h2d_done, hipEventDisableTiming) == hipSuccess;
   for (auto& ev : w->ev) ok = ok && hipEventCreate(&ev) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&w->wave_feedback, 64, hipHostMallocMapped) == hipSuccess;
   if (ok) *w->wave_feedback = 0xFFFFFFFFu;
@@ -180,6 +190,7 @@ void free_slot(Slot* w) {
   for (auto& ev : w->ev) if (ev) (void)hipEventDestroy(ev);
   if (w->done) (void)hipEventDestroy(w->done);
   if (w->host_done) (void)hipEventDestroy(w->host_done);
+  if (w->h2d_done) (void)hipEventDestroy(w->h2d_done);
   if (w->wave_feedback) (void)hipHostFree(w->wave_feedback);
   if (w->stream) (void)hipStreamDestroy(w->stream);
   delete w;
@@ -380,6 +391,8 @@ int zke_engine_create(const zke_options* opt, zke_engine** out) {
     e->slots.push_back(w);
   }
   e->stream = e->slots[0]->stream;
+  for (auto& cs : e->copy_stream)
+    if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) { zke_engine_destroy(e); return fail(nullptr, ZKE_E_DEVICE, "copy stream"); }
   if (!o.disable_key_cache) {
     const size_t kc_bytes = (size_t)KEY_CACHE_SLOTS * sizeof(KeyCacheEntry);
     if (e->key_cache.ensure(kc_bytes) || hipMemset(e->key_cache.p, 0, kc_bytes) != hipSuccess) {
@@ -410,6 +423,7 @@ void zke_engine_destroy(zke_engine* e) {
     for (Slot* w : e->slots) if (w->stream) (void)hipStreamSynchronize(w->stream);
     for (Slot* w : e->slots) free_slot(w);
     e->slots.clear();
+    for (auto& cs : e->copy_stream) if (cs) { (void)hipStreamSynchronize(cs); (void)hipStreamDestroy(cs); cs = nullptr; }
     e->misc.release(); e->key_cache.release();
     for (auto* d : e->dfas) if (d) { d->blob.release(); d->dev.release(); delete d; }
     e->dfas.clear();

@@ -308,7 +308,7 @@ int submit_host(zke_engine* e, Slot& w, const zke_batch* in, zke_result* out, bo
   const uint32_t cap_bytes = caps ? in->cap_str_off[n_caps] : 0;
   const ImageLayout L = image_layout(n, raw_total, dom_total, key_total, caps ? (size_t)n * P + 1 : 0, caps ? (size_t)n_caps + 1 : 0, cap_bytes);
   if (int r = retire_host(e, w)) return r;           // the pinned buffers are about to be overwritten
-  if (int r = ensure_host_buffers(e, w, L.total, n)) return r;
+  if (int r = ensure_host_buffers(e, w, L.total, n)) return r;      // (a no-op: the entry points have grown every slot's staging)
   uint8_t* hp = w.h_image.as<uint8_t>();
   {
     // the offsets are copied as they are (the kernels subtract off[0] themselves and the device pointers below are biased
@@ -328,7 +328,24 @@ int submit_host(zke_engine* e, Slot& w, const zke_batch* in, zke_result* out, bo
   if (int r = use.acquire()) return r;
   StageTimer tm(e, &w, s);
   tm.mark(MK_START);
-  HIPCHK(e, hipMemcpyAsync(w.d_image.p, hp, L.total, hipMemcpyHostToDevice, s));
+#ifndef ZKE_HOST_COPY_STREAM
+#define ZKE_HOST_COPY_STREAM 1
+#endif
+  if (ZKE_HOST_COPY_STREAM && L.total >= (256u << 10)) {
+    // The image crosses PCIe on one of the engine's TWO copy streams, taken in turn, and the slot's stream waits for it.  Issued
+    // on the slots' own 22 streams the input copies moved 31 GB/s in aggregate — one DMA engine's rate —, on one copy stream the
+    // same; on two, 48 GB/s = 84 % of the link (122 us per 1 024-e-mail batch instead of 186; three streams: 141 us, four: worse).
+    // Nothing on the device has to be waited for first: the slot's previous host batch — the only earlier user of d_image — was
+    // retired on the host before the image was packed.  (Small images stay on the slot's stream: the cross-stream event costs a
+    // single e-mail 16 us of latency and buys nothing.)
+    std::lock_guard<std::mutex> cg(e->copy_mu);
+    hipStream_t cs = e->copy_stream[e->copy_turn++ % ZKE_COPY_STREAMS];
+    HIPCHK(e, hipMemcpyAsync(w.d_image.p, hp, L.total, hipMemcpyHostToDevice, cs));
+    HIPCHK(e, hipEventRecord(w.h2d_done, cs));
+    HIPCHK(e, hipStreamWaitEvent(s, w.h2d_done, 0));
+  } else {
+    HIPCHK(e, hipMemcpyAsync(w.d_image.p, hp, L.total, hipMemcpyHostToDevice, s));
+  }
   tm.mark(MK_H2D);
   uint8_t* dp = w.d_image.as<uint8_t>();
   zke_batch dv = *in;
@@ -350,6 +367,39 @@ int submit_host(zke_engine* e, Slot& w, const zke_batch* in, zke_result* out, bo
   w.host_gen++;
   w.host_out = out; w.host_n = n;
   return use.release();
+}
+
+// The host entry's staging of EVERY slot, sized for images of `image` bytes and n records.  Pinned memory that comes into being
+// while other slots' copies are in flight copies at a fraction of the link's rate for the rest of its life (measured: slots that
+// allocated their staging lazily, one by one under traffic, moved 9 GB/s in aggregate; the same buffers allocated together in a
+// quiet moment 31 GB/s) — so growth is a stop-the-world event: no submission in progress (`big` exclusive), every pending host
+// batch delivered, every stream drained, then all slots at once, with headroom so that it stays rare.
+int grow_host_staging(zke_engine* e, size_t image, uint32_t n) {
+  std::unique_lock<std::shared_mutex> ex(e->big);
+  if (image <= e->host_image_cap.load() && n <= e->host_n_cap.load()) return 0;       // another thread grew it meanwhile
+  HIPCHK(e, hipSetDevice(e->device));
+  for (Slot* w : e->slots) {
+    std::lock_guard<std::mutex> g(w->mu);
+    if (int r = retire_host(e, *w)) return r;
+    if (w->last_stream && w->last_stream != w->stream) HIPCHK(e, hipEventSynchronize(w->done));
+    HIPCHK(e, hipStreamSynchronize(w->stream));
+  }
+  const size_t want_image = std::max(image + image / 2, e->host_image_cap.load());
+  const uint32_t want_n = std::max<uint32_t>(n + n / 2, e->host_n_cap.load());
+  for (Slot* w : e->slots)
+    if (int r = ensure_host_buffers(e, *w, want_image, want_n)) return r;
+  e->host_image_cap = want_image;
+  e->host_n_cap = want_n;
+  return 0;
+}
+// what one batch needs of the staging (image_layout of its sizes)
+size_t host_image_bytes(const zke_batch* in) {
+  const uint32_t n = in->n;
+  const uint32_t P = in->with_regex ? in->n_header_parts + in->n_body_parts : 0;
+  const bool caps = P && in->cap_off;
+  const uint32_t n_caps = caps ? in->cap_off[(size_t)n * P] : 0;
+  return image_layout(n, in->raw_off[n] - in->raw_off[0], in->domain_off[n] - in->domain_off[0], in->key_off[n] - in->key_off[0],
+                      caps ? (size_t)n * P + 1 : 0, caps ? (size_t)n_caps + 1 : 0, caps ? in->cap_str_off[n_caps] : 0).total;
 }
 
 int check_host_batch(zke_engine* e, const zke_batch* in, zke_result* out, const char* who) {
@@ -521,6 +571,7 @@ int zke_engine_reserve(zke_engine* e, uint32_t max_n, uint64_t max_raw_total, ui
   if (max_n)
     for (Slot* w : e->slots)
       if (int r = ensure_workspace(e, *w, max_n, max_raw_total, max_regex_parts != 0, max_regex_parts, false)) return r;
+
   // A stream's hardware queue and the queue's scratch memory (the front end spills a few registers) come into being
   // with the first launch that needs them — milliseconds, and they would land in the first batch of every slot.
   // One trivial launch per slot, with more scratch per lane than any kernel of the pipeline, pays for both here.
@@ -549,18 +600,18 @@ int zke_engine_reserve(zke_engine* e, uint32_t max_n, uint64_t max_raw_total, ui
   e->timing = timing;
   HIPCHK(e, hipGetLastError());
   for (Slot* w : e->slots) HIPCHK(e, hipStreamSynchronize(w->stream));
+  if (e->host_image_cap.load())          // slots created just now get the staging the others have (everything is drained: see grow_host_staging)
+    for (Slot* w : e->slots)
+      if (int r = ensure_host_buffers(e, *w, e->host_image_cap.load(), e->host_n_cap.load())) return r;
   return 0;
 }
 
 int zke_engine_reserve_host(zke_engine* e, uint32_t max_n, uint64_t max_input_bytes) {
   if (!e) return ZKE_E_ARG;
-  std::unique_lock<std::shared_mutex> ex(e->big);
-  HIPCHK(e, hipSetDevice(e->device));
   // offsets, key types and 64-byte alignment on top of the blobs (image_layout)
   const size_t image = (size_t)max_input_bytes + (size_t)(max_n + 1) * 24 + 2 * (size_t)max_n + 16 * 64 + 4 * 64;
-  for (Slot* w : e->slots)
-    if (int r = ensure_host_buffers(e, *w, image, max_n)) return r;
-  return 0;
+  if (image <= e->host_image_cap.load() && max_n <= e->host_n_cap.load()) return 0;
+  return grow_host_staging(e, image, max_n);
 }
 
 int zke_verify_batch_device(zke_engine* e, const zke_batch* in, uint64_t raw_total, uint64_t domain_total, uint64_t key_total,
@@ -650,6 +701,7 @@ int zke_verify_batch_device(zke_engine* e, const zke_batch* in, uint64_t raw_tot
 int zke_verify_batch_async(zke_engine* e, const zke_batch* in, zke_result* out, uint64_t* ticket) {
   if (int r = check_host_batch(e, in, out, "zke_verify_batch_async: null pointer")) return r;
   if (!ticket) return fail(e, ZKE_E_ARG, "zke_verify_batch_async: null ticket");
+  if (in->n) { const size_t img = host_image_bytes(in); if (img > e->host_image_cap.load() || in->n > e->host_n_cap.load()) if (int r = grow_host_staging(e, img, in->n)) return r; }
   std::shared_lock<std::shared_mutex> sh(e->big);
   HIPCHK(e, hipSetDevice(e->device));
   uint32_t slot;
@@ -678,6 +730,7 @@ int zke_verify_batch(zke_engine* e, const zke_batch* in, zke_result* out, zke_de
   if (int r = check_host_batch(e, in, out, "zke_verify_batch: null pointer")) return r;
   const uint32_t n = in->n;
   if (n == 0) return 0;
+  { const size_t img = host_image_bytes(in); if (img > e->host_image_cap.load() || n > e->host_n_cap.load()) if (int r = grow_host_staging(e, img, n)) return r; }
   std::shared_lock<std::shared_mutex> sh(e->big);
   HIPCHK(e, hipSetDevice(e->device));
   uint32_t slot;
