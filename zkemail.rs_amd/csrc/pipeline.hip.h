@@ -384,6 +384,8 @@ int grow_host_staging(zke_engine* e, size_t image, uint32_t n) {
     if (w->last_stream && w->last_stream != w->stream) HIPCHK(e, hipEventSynchronize(w->done));
     HIPCHK(e, hipStreamSynchronize(w->stream));
   }
+  for (auto& cs : e->copy_stream)
+    if (!cs) HIPCHK(e, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
   const size_t want_image = std::max(image + image / 2, e->host_image_cap.load());
   const uint32_t want_n = std::max<uint32_t>(n + n / 2, e->host_n_cap.load());
   for (Slot* w : e->slots)
