@@ -540,20 +540,22 @@ def cpu_model() -> str:
 
 def load_profile_figures(args, n):
     """PMC figures of the bench workload from the committed rocprofv3 summaries (profiles/, newest round first): the VALU / SALU
-    wave-instructions of one batch (sum over its three launches) and the HBM bytes of the hash / modexp launch.  Only for the
-    workload they were taken on (c2 at its configured batch size); None otherwise."""
+    wave-instructions of one batch (sum over all its launches) and, for configs[1], the HBM bytes of the hash / modexp launch.
+    Only for the workload they were taken on at its configured batch size; empty otherwise."""
     out = {}
-    if args.workload != "c2" or args.batch:
+    if args.batch:
         return out
     for rnd in ("r03", "r02", "r01"):
-        f = os.path.join(ROOT, "profiles", f"{rnd}_c2_instr_pmc.json")
+        f = os.path.join(ROOT, "profiles", f"{rnd}_{args.workload}_instr_pmc.json")
         if os.path.exists(f):
             j = json.load(open(f))
-            ks = [k for k in j if any(t in k for t in ("parse_kernel", "hash_modexp_kernel", "ed_verdict_kernel"))]
+            ks = [k for k in j if "zke::" in k and "slot_warm" not in k and "sha_jobs_from_csr" not in k]
             out["valu_per_batch"] = round(sum(j[k]["SQ_INSTS_VALU"] for k in ks))
             out["salu_per_batch"] = round(sum(j[k]["SQ_INSTS_SALU"] for k in ks))
-            out["instr_source"] = f"profiles/{rnd}_c2_instr_pmc.json"
+            out["instr_source"] = f"profiles/{rnd}_{args.workload}_instr_pmc.json"
             break
+    if args.workload != "c2":
+        return out
     for rnd in ("r03", "r02", "r01"):
         f = os.path.join(ROOT, "profiles", f"{rnd}_c2_sha_pmc.json")
         if os.path.exists(f):
