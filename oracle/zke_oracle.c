@@ -1017,6 +1017,8 @@ static int dfa_parse(const uint8_t* b, size_t n, dfa_t* d) {
   if (d->stride2 < 1 || d->stride2 > 9) return sec;
   d->alphabet_len = (uint32_t)d->classes[255] + 2;
   if (d->alphabet_len > (1u << d->stride2)) return sec;
+  for (int i = 0; i < 256; i++)                    /* ByteClasses::from_bytes: no class beyond the alphabet (a walk would leave the checked columns) */
+    if (d->classes[i] >= d->alphabet_len) return sec;
   if (d->state_len > (1u << 26)) return sec;
   d->table_len = (size_t)d->state_len << d->stride2;
   NEED(d->table_len * 4);

@@ -66,6 +66,9 @@ def damaged_blobs():
                 ("big-endian marker", put(32, 0xFFFE0000), A.D_DFA_ENDIAN_VERSION),
                 ("version 3", put(36, 3), A.D_DFA_ENDIAN_VERSION),
                 ("stride2 = 0", put(52, 0), A.D_DFA_TRANSITIONS),
+                # a byte class beyond the alphabet: table[state + class] would land in columns nobody id-checked (found by
+                # tests/cpp/host_fuzz.cpp; ByteClasses::from_bytes rejects it too)
+                ("class beyond the alphabet", good[:56 + 65] + bytes([good[56 + 255] + 2]) + good[56 + 66:], A.D_DFA_TRANSITIONS),
                 ("unaligned transition", put(48 + 8 + 256 + 4 * (1 << struct.unpack_from('<I', good, 52)[0]), 3), A.D_DFA_TRANSITIONS),
                 ("start kind 7", put(st[A.D_DFA_START_TABLE], 7), A.D_DFA_START_TABLE),
                 ("start stride 5", put(st[A.D_DFA_START_TABLE] + 4 + 256, 5), A.D_DFA_START_TABLE),

@@ -69,6 +69,8 @@ uint32_t parse_dfa_blob(const uint8_t* b, size_t n, HostDfa& h) {
   if (d.stride2 < 1 || d.stride2 > 9) return ZKE_D_DFA_TRANSITIONS;
   d.alphabet_len = (uint32_t)d.classes[255] + 2;
   if (d.alphabet_len > (1u << d.stride2)) return ZKE_D_DFA_TRANSITIONS;
+  for (int i = 0; i < 256; i++)          // ByteClasses::from_bytes: no class beyond the alphabet — the walk indexes table[sid + class]
+    if (d.classes[i] >= d.alphabet_len) return ZKE_D_DFA_TRANSITIONS;   // and only columns < alphabet_len are id-checked below
   if (d.state_len > (1u << 26)) return ZKE_D_DFA_TRANSITIONS;
   const size_t tl = (size_t)d.state_len << d.stride2;
   if (!need(tl * 4)) return ZKE_D_DFA_TRANSITIONS;
