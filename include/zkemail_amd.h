@@ -163,8 +163,10 @@ typedef struct zke_result {
 
 /* ------------------------------------------------------------------ batch input */
 /* Struct-of-arrays view of &[Email] / &[EmailWithRegex] (core/src/structs.rs:49-62).
- * Caller-owned, read-only for the call.  In zke_verify_batch the pointers are host
- * memory; in zke_verify_batch_device they are device (HBM) pointers. */
+ * Caller-owned, read-only for the call.  In zke_verify_batch / zke_verify_batch_async the
+ * pointers are host memory and every offset array is checked to be non-decreasing before
+ * anything is copied (ZKE_E_ARG otherwise); in zke_verify_batch_device they are device (HBM)
+ * pointers and the offsets are trusted like the pointers themselves. */
 typedef struct zke_batch {
   uint32_t n;                      /* emails */
   const uint8_t*  raw_blob;        /* Email.raw_email, concatenated            structs.rs:51 */

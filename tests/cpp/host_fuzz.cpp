@@ -5,7 +5,8 @@
 //   * zke_wire_decode: borsh / bincode records cut at every length and with random byte flips;
 //   * CopyPool: several callers at once, odd sizes and alignments, results compared with memcpy (also under -fsanitize=thread);
 //   * zke_shard_bounds, image_layout, pair_hash on edge sizes.
-// tests/test_host_sanitizers.py builds and runs it.
+// tests/test_host_sanitizers.py builds and runs it.  (The same source with -fsanitize=thread instead: clean as well, run by hand —
+// the second 40 s build is not worth a place in the suite.)
 #include "../../zkemail.rs_amd/csrc/engine.hip"
 
 #include <random>

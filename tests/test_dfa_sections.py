@@ -148,3 +148,54 @@ def test_unregister_and_registry_cap(oracle):
             eng2.close()
     finally:
         eng.close()
+
+
+@pytest.mark.gpu
+def test_per_email_regex_calls_from_four_threads_through_a_full_registry():
+    """96 distinct pairs through a registry of 64 from four threads at once: registrations evict each other's pairs all the
+    time and ids change hands, yet every call must be checked against ITS pattern — the pairs of a call in progress are pinned
+    (csrc/pipeline.hip.h, dfa_register_impl / dfa_unpin).  Pattern k matches one six-byte window of the subject and the
+    call's capture is that window: under any other pattern of the set the capture is contained in no match (regex.rs:41-47)
+    and the call panics."""
+    import threading
+
+    import synth
+    import zkemail_rs_amd as z
+    eng = z.Engine(max_dfas=64, slots=3)
+    try:
+        inputs, wl, _ = synth.make_regex_workload("pins", 2, 500, n_header_parts=1, n_body_parts=0, seed=6)
+        base = inputs[0]
+        subject = [ln for ln in base.email.raw_email.split(b"\r\n") if ln.lower().startswith(b"subject:")][0].split(b":", 1)[1].strip().decode()
+        windows = [subject[k:k + 6] for k in range(32)]
+        assert len(set(windows)) == 32 and all(subject.count(w) == 1 for w in windows)
+        esc = lambda s: "".join(c if c.isalnum() else "\\x%02x" % ord(c) for c in s)
+        ones, want = [], []
+        for w in windows:
+            for v in "ABC":
+                ones.append(A.EmailWithRegex(base.email, A.RegexInfo([A.CompiledRegex(rc.create_dfa(esc(w) + "|zz" + v), [w])], None)))
+                want.append([w])
+        for one, m in zip(ones, want):                              # serially first: every call passes with its own pattern ...
+            assert eng.verify_email_with_regex(one).regex_matches == m
+        wrong = A.EmailWithRegex(base.email, A.RegexInfo([A.CompiledRegex(ones[0].regex_info.header_parts[0].verify_re, [windows[9]])], None))
+        with pytest.raises(z.VerifyPanic):                          # ... and panics with another one's capture
+            eng.verify_email_with_regex(wrong)
+        errors = []
+
+        def worker(tid):
+            try:
+                for it in range(150):
+                    k = (tid * 29 + it * 7) % len(ones)
+                    if eng.verify_email_with_regex(ones[k]).regex_matches != want[k]:
+                        raise AssertionError(f"thread {tid} call {it}")
+            except Exception as ex:
+                errors.append(f"thread {tid}: {ex!r}")
+
+        ths = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join(timeout=300)
+        assert not errors, errors[:3]
+        assert not any(t.is_alive() for t in ths)
+    finally:
+        eng.close()

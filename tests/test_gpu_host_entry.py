@@ -192,3 +192,26 @@ def test_length_buckets_across_slot_reuse(oracle):
         assert n_ok == sum(1 for it in packs[0][2].inter if it["corrupt"] is None) and 0 < n_ok < 700
     finally:
         eng.close()
+
+
+def test_host_offsets_are_checked(oracle):
+    """Offset arrays in host memory are validated before anything is staged (csrc/pipeline.hip.h, check_host_batch): a length
+    that comes out negative is ZKE_E_ARG, not a copy outside the blob; the engine stays usable."""
+    import zkemail_rs_amd as z
+    eng = z.Engine()
+    try:
+        (p, _) = _batches(1, n=16, seed0=650)[0]
+        good = eng.verify_batch(p)
+        for arr in (p.raw_off, p.domain_off, p.key_off):
+            keep = arr.copy()
+            arr[5], arr[6] = keep[6], keep[5]                      # (the arrays are the ones the zke_batch points to)
+            if arr[5] == arr[6]:
+                arr[5] += 1
+            with pytest.raises(z.EngineError, match="non-decreasing"):
+                eng.verify_batch(p)
+            with pytest.raises(z.EngineError, match="non-decreasing"):
+                eng.verify_batch_async(p)
+            arr[:] = keep
+        assert_records_equal(eng.verify_batch(p), good, None, "after the refused batches")
+    finally:
+        eng.close()

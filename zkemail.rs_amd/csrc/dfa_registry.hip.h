@@ -149,6 +149,8 @@ struct RegisteredDfa {
   uint64_t hash = 0;        // pair_hash of them: the registry's key
   bool transient = false;   // registered by zke_verify_email_with_regex on its own: may be evicted when the registry is full
   std::atomic<uint64_t> last_use{0};   // registry clock at the last registration / lookup hit
+  std::atomic<uint32_t> pins{0};       // per-e-mail calls between their registration and the end of their batch: not evictable,
+                                       // not unregistrable — an id must not change hands under a call that is about to use it
 };
 
 // 64-bit hash of a blob pair, eight bytes per step (a per-e-mail caller re-submits its part list with every e-mail: the

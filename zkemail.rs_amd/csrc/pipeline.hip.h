@@ -411,6 +411,18 @@ int check_host_batch(zke_engine* e, const zke_batch* in, zke_result* out, const 
     return fail(e, ZKE_E_ARG, who);
   if (in->with_regex && ((in->n_header_parts && !in->header_part_ids) || (in->n_body_parts && !in->body_part_ids)))
     return fail(e, ZKE_E_ARG, "part-id list is null");
+  // The offset arrays are in host memory here, so they are checked (three passes over n + 1 words): a length that came out
+  // negative would send the staging copy, and then the kernels, outside the blobs.  (In device memory — zke_verify_batch_device —
+  // they are the caller's to get right, like the pointers themselves.)
+  auto rising = [](const auto* off, size_t cnt) { uint64_t bad = 0; for (size_t i = 0; i < cnt; i++) bad |= (uint64_t)(off[i + 1] < off[i]); return !bad; };
+  if (in->n && !(rising(in->raw_off, in->n) && rising(in->domain_off, in->n) && rising(in->key_off, in->n)))
+    return fail(e, ZKE_E_ARG, "offset array is not non-decreasing");
+  if (in->n && in->raw_off[in->n] - in->raw_off[0] > (1ull << 40)) return fail(e, ZKE_E_ARG, "raw blob beyond 1 TiB");
+  if (in->with_regex && in->cap_off) {
+    const size_t NP = (size_t)in->n * ((size_t)in->n_header_parts + in->n_body_parts);
+    if (NP && (!rising(in->cap_off, NP) || (in->cap_off[NP] && (!in->cap_str_off || !in->cap_blob || !rising(in->cap_str_off, in->cap_off[NP])))))
+      return fail(e, ZKE_E_ARG, "capture offset array is not non-decreasing");
+  }
   return 0;
 }
 
@@ -428,13 +440,14 @@ void drop_dfa(zke_engine* e, uint32_t id) {
 }
 
 // (caller holds reg_mu, shared or exclusive)
-bool dfa_lookup(zke_engine* e, uint64_t h, const uint8_t* fwd, size_t fl, const uint8_t* bwd, size_t bl, uint32_t* id) {
+bool dfa_lookup(zke_engine* e, uint64_t h, const uint8_t* fwd, size_t fl, const uint8_t* bwd, size_t bl, uint32_t* id, bool pin) {
   auto range = e->dfa_index.equal_range(h);
   for (auto it = range.first; it != range.second; ++it) {
     RegisteredDfa* d = e->dfas[it->second];
     if (d && d->fwd_copy.size() == fl && d->bwd_copy.size() == bl && (!fl || !memcmp(d->fwd_copy.data(), fwd, fl)) &&
         (!bl || !memcmp(d->bwd_copy.data(), bwd, bl))) {
       d->last_use.store(e->reg_clock.fetch_add(1) + 1, std::memory_order_relaxed);
+      if (pin) d->pins.fetch_add(1);
       *id = it->second;
       return true;
     }
@@ -456,20 +469,21 @@ int dfa_evict_one(zke_engine* e) {
   uint64_t oldest = ~0ull;
   for (uint32_t k = 0; k < e->dfas.size(); k++) {
     const RegisteredDfa* d = e->dfas[k];
-    if (d && d->transient && d->last_use.load(std::memory_order_relaxed) < oldest) { oldest = d->last_use.load(std::memory_order_relaxed); victim = k; }
+    if (d && d->transient && !d->pins.load() && d->last_use.load(std::memory_order_relaxed) < oldest) { oldest = d->last_use.load(std::memory_order_relaxed); victim = k; }
   }
-  if (victim == 0xFFFFFFFFu) return fail(e, ZKE_E_NOMEM, "DFA registry full (zke_options.max_dfas): zke_dfa_unregister pairs no longer needed");
+  if (victim == 0xFFFFFFFFu) return fail(e, ZKE_E_NOMEM, "DFA registry full (zke_options.max_dfas): zke_dfa_unregister pairs no longer needed (pairs of per-e-mail calls in progress cannot be evicted)");
   drop_dfa(e, victim);
   return 0;
 }
 
+// transient: registered by a per-e-mail call on its own — evictable, and PINNED for the caller (dfa_unpin when its batch is done)
 int dfa_register_impl(zke_engine* e, const uint8_t* fwd, size_t fwd_len, const uint8_t* bwd, size_t bwd_len, uint32_t* out_id, bool transient) {
   if (!e || !out_id || (fwd_len && !fwd) || (bwd_len && !bwd)) return ZKE_E_ARG;
   const uint64_t h = pair_hash(fwd, fwd_len, bwd, bwd_len);
   {
     // registering the same pair again returns the id it already has (per-e-mail callers re-submit their part list)
     std::shared_lock<std::shared_mutex> rl(e->reg_mu);
-    if (dfa_lookup(e, h, fwd, fwd_len, bwd, bwd_len, out_id)) return 0;
+    if (dfa_lookup(e, h, fwd, fwd_len, bwd, bwd_len, out_id, transient)) return 0;
   }
   HIPCHK(e, hipSetDevice(e->device));
   RegisteredDfa* rd = new RegisteredDfa();
@@ -509,7 +523,7 @@ int dfa_register_impl(zke_engine* e, const uint8_t* fwd, size_t fwd_len, const u
   for (;;) {
     {
       std::unique_lock<std::shared_mutex> rl(e->reg_mu);
-      if (dfa_lookup(e, h, fwd, fwd_len, bwd, bwd_len, out_id)) { discard(); return 0; }      // another thread was first
+      if (dfa_lookup(e, h, fwd, fwd_len, bwd, bwd_len, out_id, transient)) { discard(); return 0; }      // another thread was first
       if (e->dfa_live < e->opt.max_dfas) {
         if (rd->valid && rd->lds_bytes + 1024 <= 150 * 1024)       // the tables fit in LDS: the DFA kernels are launched with that much
           if (int r = raise_dfa_lds_attrs(e, rd->lds_bytes + 1024)) { discard(); return r; }
@@ -517,6 +531,7 @@ int dfa_register_impl(zke_engine* e, const uint8_t* fwd, size_t fwd_len, const u
         while (id < e->dfas.size() && e->dfas[id]) id++;
         if (id == e->dfas.size()) e->dfas.push_back(nullptr);
         rd->last_use.store(e->reg_clock.fetch_add(1) + 1, std::memory_order_relaxed);
+        rd->pins.store(transient ? 1u : 0u);
         e->dfas[id] = rd;
         e->dfa_index.emplace(h, id);
         e->dfa_live++;
@@ -526,6 +541,11 @@ int dfa_register_impl(zke_engine* e, const uint8_t* fwd, size_t fwd_len, const u
     }
     if (int r = dfa_evict_one(e)) { discard(); return r; }
   }
+}
+
+void dfa_unpin(zke_engine* e, const std::vector<uint32_t>& ids) {
+  std::shared_lock<std::shared_mutex> rl(e->reg_mu);
+  for (uint32_t id : ids) e->dfas[id]->pins.fetch_sub(1);          // (a pinned entry is neither evicted nor unregistered: it is there)
 }
 
 // tickets: slot index in the low 6 bits (an engine has at most 64 slots), the slot's batch count above
@@ -557,6 +577,7 @@ int zke_dfa_unregister(zke_engine* e, uint32_t id) {
   }
   std::unique_lock<std::shared_mutex> rl(e->reg_mu);
   if (id >= e->dfas.size() || !e->dfas[id]) return fail(e, ZKE_E_DFA, "zke_dfa_unregister: id is not registered");
+  if (e->dfas[id]->pins.load()) return fail(e, ZKE_E_DFA, "zke_dfa_unregister: a zke_verify_email_with_regex call in progress uses this pair");
   drop_dfa(e, id);
   return 0;
 }
@@ -824,6 +845,9 @@ int zke_verify_email_with_regex(zke_engine* e, const uint8_t* raw, size_t raw_le
   OneEmail one(raw, raw_len, from_domain, domain_len, key, key_len, key_type, external_input_null);
   std::vector<uint32_t> hids, bids, cap_off{0}, str_off{0};
   std::vector<uint8_t> blob;
+  // every pair this call registers or finds stays pinned until the batch has run: with the registry at its cap another
+  // thread's registration evicts the least recently used transient pair and the id is handed out again
+  struct Pins { zke_engine* e; std::vector<uint32_t> ids; ~Pins() { if (!ids.empty()) dfa_unpin(e, ids); } } pinned{e, {}};
   for (int side = 0; side < 2; side++) {
     const zke_regex_part* parts = side ? body_parts : header_parts;
     const uint32_t np = side ? n_body_parts : n_header_parts;
@@ -834,6 +858,7 @@ int zke_verify_email_with_regex(zke_engine* e, const uint8_t* raw, size_t raw_le
       uint32_t id = 0;
       // the same pair gets the same id: a hash lookup, not a parse; pairs registered here are the evictable ones
       if (int r = dfa_register_impl(e, p.fwd, p.fwd_len, p.bwd, p.bwd_len, &id, true)) return r;
+      pinned.ids.push_back(id);
       (side ? bids : hids).push_back(id);
       for (uint32_t c = 0; c < p.n_captures; c++) {
         if (p.capture_lens[c] && !p.captures[c]) return fail(e, ZKE_E_ARG, "zke_verify_email_with_regex: null capture");
