@@ -29,8 +29,32 @@ def run(steps):
     for t in ring:
         if t is not None: lib.zke_batch_wait(h, t)
     return (time.perf_counter() - t0) / steps
+def run_threads(steps, T):
+    """T submitting threads, each with its own ring of S // T tickets (ctypes drops the GIL inside the calls)."""
+    import threading
+    per = steps // T
+    def work(j):
+        R = max(1, S // T)
+        ring = [None] * R
+        o = [np.zeros(p.n, dtype=A.RESULT_DTYPE) for _ in range(R)]
+        for i in range(per):
+            k = i % R
+            if ring[k] is not None: lib.zke_batch_wait(h, ring[k])
+            t = C.c_uint64(); assert lib.zke_verify_batch_async(h, C.byref(p.c), o[k].ctypes.data, C.byref(t)) == 0; ring[k] = t.value
+        for t in ring:
+            if t is not None: lib.zke_batch_wait(h, t)
+    ths = [threading.Thread(target=work, args=(j,)) for j in range(T)]
+    t0 = time.perf_counter()
+    for t in ths: t.start()
+    for t in ths: t.join()
+    return (time.perf_counter() - t0) / (per * T)
 run(3 * S)
 print("slots", S, "us per batch untimed", round(run(40 * S) * 1e6, 1))
+for a in sys.argv:
+    if a.startswith("threads="):
+        for T in [int(x) for x in a.split("=")[1].split(",")]:
+            run_threads(4 * S, T)
+            print("submit threads", T, "us per batch", [round(run_threads(40 * S, T) * 1e6, 1) for _ in range(3)])
 eng.set_timing(True)
 print("us per batch with marks", round(run(20 * S) * 1e6, 1))
 rows = [eng.slot_timings(k) for k in range(S)]
