@@ -159,6 +159,11 @@ class Oracle:
             self._dfa_cache[key] = out.value
         return self._dfa_cache[key]
 
+    def dfa_reset(self):
+        """Forget every registered pair (the oracle's table is a fixed array; a test that registers hundreds clears it)."""
+        self.lib.zko_dfa_reset()
+        self._dfa_cache.clear()
+
     def find_iter(self, dfa_id: int, hay: bytes, max_spans: int = 64):
         sp = (C.c_uint32 * (2 * max_spans))()
         n = self.lib.zko_regex_find_iter(dfa_id, self._buf(hay), len(hay), C.addressof(sp), max_spans)

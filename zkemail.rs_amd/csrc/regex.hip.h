@@ -364,8 +364,9 @@ __device__ __forceinline__ PartRes dfa_part(const DfaArgs& A, const DfaLds& F, c
       if (r == 0) break;
     }
     if (count == 0) { fs = ms; fe = me; }
-    count++;
-    if (count >= 2) break;                     // "exactly one" is already decided
+    if (count < 2) count++;                    // (the record's count saturates at 2)
+    // no early exit at the second match: the reference collects the WHOLE iterator (regex.rs:36) before it counts, so a quit
+    // state further on is still a panic (ZKE_D_RE_QUIT), not a miscount — found by tests/test_gpu_regex.py::test_mutated_automata_parity
     start = me; have_last = true; last_end = me;
   }
   pr.count = count; pr.start = fs; pr.end = fe; pr.code = 0;
