@@ -285,3 +285,70 @@ def test_mutated_automata_parity(oracle, mapping):
     engine.close()
     # one match, a wrong count, and a panic (quit state, or a reverse walk that finds no start) are all reached
     assert {(A.ZKE_OK, 0), (A.ZKE_BODY_REGEX_FAIL, A.D_RE_MATCH_COUNT), (A.ZKE_BODY_REGEX_FAIL, A.D_RE_QUIT)} <= seen, seen
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_capture_containment_fuzz_parity(engine, oracle, seed):
+    """`String::from_utf8_lossy(match).contains(capture)` (core/src/regex.rs:43-44) over match texts that are ASCII, multi-byte
+    UTF-8 and broken UTF-8 (truncated sequences, overlongs, surrogates, lone continuation bytes, 0xF5..0xFF), with captures
+    cut from the lossy decoding (U+FFFD included), from elsewhere, empty, and several per part: whatever the oracle decides
+    — contained, missing, or the unsupported U+FFFD case — the device decides the same."""
+    rng = np.random.default_rng(seed)
+    k0 = synth.load_keys()["rsa2048_00"]
+    hdrs = synth.std_headers(np.random.default_rng(1), 1, "example.com")
+    d = rc.create_dfa(r"<<[^>]*>>")
+    pieces = [b"plain", b"caf\xc3\xa9", b"\xe2\x82\xac", b"\xf0\x9f\x98\x80", b"\xc3", b"\xe2\x82", b"\xf0\x9f\x98", b"\x80", b"\xbf\xbf",
+              b"\xc0\xaf", b"\xe0\x80\xaf", b"\xed\xa0\x80", b"\xf4\x90\x80\x80", b"\xf5", b"\xff", b" ", b"=", b"\xef\xbf\xbd", b"x" * 40]
+    ins = []
+    for k in range(300):
+        inner = b"".join(pieces[int(i)] for i in rng.integers(0, len(pieces), int(rng.integers(0, 9))))
+        body = b"lead " + b"<<" + inner + b">>" + b" tail\r\n"
+        raw, _ = synth.sign_email(hdrs, body, k0, synth.SignSpec(header_canon="simple", body_canon="simple"))
+        text = (b"<<" + inner + b">>").decode("utf-8", "replace")
+        caps = []
+        for _ in range(int(rng.integers(0, 4))):
+            r = rng.random()
+            if r < 0.55 and text:
+                a = int(rng.integers(0, len(text))); b = int(rng.integers(a, len(text) + 1))
+                caps.append(text[a:b])
+            elif r < 0.7:
+                caps.append("")
+            elif r < 0.85:
+                caps.append(["nowhere", "�", "é", "<<>", ">>x", "😀"][int(rng.integers(0, 6))])
+            else:
+                caps.append(text + "z")
+        ins.append(A.EmailWithRegex(A.Email("example.com", raw, A.PublicKey(k0.pkcs1_der)),
+                                    A.RegexInfo(None, [A.CompiledRegex(d, caps if rng.random() < 0.9 else None)])))
+    got = engine.verify_batch(engine.pack_with_regex(ins))
+    exp = oracle.verify_batch(oracle.pack_with_regex(ins), threads=4)
+    assert_records_equal(got, exp, None, "capture fuzz")
+    assert len({(int(s), int(x)) for s, x in zip(exp["status"], exp["detail"])}) >= 3
+
+
+@pytest.mark.parametrize("seed,body_canon", [(31, "simple"), (32, "relaxed")])
+def test_qp_soft_break_filter_adversarial_parity(engine, oracle, seed, body_canon):
+    """remove_quoted_printable_soft_breaks (circuits.rs:37) over bodies made of `=`, CR LF and a few letters in random order:
+    `==CRLF`, `=CR=CRLF`, runs of `=CRLF`, a break at offset 0 and at the very end, breaks that appear only once relaxed
+    canonicalisation has removed the blanks before the CRLF, and all of it sliding across the 64-byte steps of the device
+    filter (shifted ballots, csrc/regex.hip.h qp_wave).  The cleaned body (bytes and zero padding) and the records of a
+    body part over it are the oracle's."""
+    rng = np.random.default_rng(seed)
+    k0 = synth.load_keys()["rsa2048_00"]
+    hdrs = synth.std_headers(np.random.default_rng(1), 1, "example.com")
+    toks = [b"=", b"\r\n", b"=\r\n", b"=\r\n", b"=\r", b"a", b"abc", b"=3D", b" ", b"= \r\n", b"=\t\r\n", b"x" * 61, b"y" * 125]
+    d = rc.create_dfa(r"abc")
+    ins = []
+    for k in range(240):
+        n = int(rng.integers(0, 40))
+        body = b"".join(toks[int(i)] for i in rng.integers(0, len(toks), n))
+        if k % 5 == 0:
+            body = b"=\r\n" * int(rng.integers(1, 70))                       # nothing but breaks
+        if k % 7 == 0:
+            body = b"z" * int(rng.integers(55, 70)) + body                   # push the mix across a step boundary
+        body += [b"\r\n", b"", b"=\r\n", b"="][int(rng.integers(0, 4))]
+        raw, _ = synth.sign_email(hdrs, body, k0, synth.SignSpec(header_canon="relaxed", body_canon=body_canon))
+        ins.append(A.EmailWithRegex(A.Email("example.com", raw, A.PublicKey(k0.pkcs1_der)), A.RegexInfo(None, [A.CompiledRegex(d, None)])))
+    got, exp, d1, d2 = both(engine, oracle, ins)
+    assert_records_equal(got, exp, None, "qp fuzz")
+    assert (d1.clean_body == d2.clean_body).all()
+    assert (np.asarray(exp["status"]) == A.ZKE_OK).sum() > 20 and (np.asarray(exp["status"]) == A.ZKE_BODY_REGEX_FAIL).sum() > 20
