@@ -4,6 +4,7 @@
 //     with every byte of their headers flipped, and random word substitutions;
 //   * zke_wire_decode: borsh / bincode records cut at every length and with random byte flips;
 //   * CopyPool: several callers at once, odd sizes and alignments, results compared with memcpy (also under -fsanitize=thread);
+//   * zke_abi_encode into buffers of exactly the size it asks for, and one byte less;
 //   * zke_shard_bounds, image_layout, pair_hash on edge sizes.
 // tests/test_host_sanitizers.py builds and runs it.  (The same source with -fsanitize=thread instead: clean as well, run by hand —
 // the second 40 s build is not worth a place in the suite.)
@@ -106,6 +107,25 @@ int main(int argc, char** argv) {
     for (auto& t : ths) t.join();
     if (bad) { fprintf(stderr, "CopyPool: %d copies differ from memcpy\n", bad.load()); return 1; }
     cases += 240;
+  }
+  // ---- zke_abi_encode: string tables of random sizes into heap buffers of exactly the size asked for, one byte less, and none
+  for (int it = 0; it < 3000; it++) {
+    uint8_t h1[32], h2[32];
+    for (int i = 0; i < 32; i++) { h1[i] = (uint8_t)rng(); h2[i] = (uint8_t)rng(); }
+    auto table = [&](std::vector<std::vector<uint8_t>>& store, std::vector<const uint8_t*>& ptr, std::vector<size_t>& len) {
+      const int n = (int)(rng() % 5);
+      for (int i = 0; i < n; i++) { store.emplace_back((size_t)(rng() % 3 == 0 ? rng() % 100 : rng() % 34)); for (auto& c : store.back()) c = (uint8_t)rng(); }
+      for (auto& v : store) { ptr.push_back(v.empty() ? nullptr : v.data()); len.push_back(v.size()); }
+    };
+    std::vector<std::vector<uint8_t>> s1, s2; std::vector<const uint8_t*> p1, p2; std::vector<size_t> l1, l2;
+    table(s1, p1, l1); table(s2, p2, l2);
+    const uint32_t wm = (uint32_t)(rng() & 1);
+    size_t need = 0, got = 0;
+    if (zke_abi_encode(h1, h2, p1.data(), l1.data(), (uint32_t)p1.size(), wm, p2.data(), l2.data(), (uint32_t)p2.size(), nullptr, 0, &need) != 0 || need % 32) { fprintf(stderr, "abi size query\n"); return 1; }
+    std::vector<uint8_t> exact(need), tight(need - 1);
+    if (zke_abi_encode(h1, h2, p1.data(), l1.data(), (uint32_t)p1.size(), wm, p2.data(), l2.data(), (uint32_t)p2.size(), exact.data(), exact.size(), &got) != 0 || got != need) { fprintf(stderr, "abi exact\n"); return 1; }
+    if (zke_abi_encode(h1, h2, p1.data(), l1.data(), (uint32_t)p1.size(), wm, p2.data(), l2.data(), (uint32_t)p2.size(), tight.data(), tight.size(), &got) != ZKE_E_NOMEM) { fprintf(stderr, "abi tight\n"); return 1; }
+    cases++;
   }
   // ---- small pure functions on edge sizes
   {
