@@ -139,6 +139,71 @@ def test_mutation_fuzz_parity(engine, oracle, seed):
     assert_records_equal(got, exp, None, "fuzz")
 
 
+@pytest.mark.parametrize("seed", [41, 42])
+def test_signature_list_fuzz_parity(engine, oracle, seed):
+    """Up to seven DKIM-Signature headers per message, in random file order and at random places of the header block: the good
+    one (or none), foreign-domain ones (skipped), same-domain ones that fail by body hash, by a flipped bit of b=, by the
+    wrong key, by a missing tag, an Ed25519 one beside an RSA key, simple / relaxed mixes.  cfdkim takes them in file order
+    and stops at the first same-domain pass; the record (status, detail, sig_index, flags, hashes) must be the oracle's."""
+    from synth import SignSpec, sign_email
+    rng = np.random.default_rng(seed)
+    k0, k1 = cases.K("rsa2048_00"), cases.K("rsa2048_01")
+    ed = cases.ED()[0]
+    emails = []
+    for k in range(220):
+        hs, body = cases._hdrs(50 + k), cases._body(int(rng.integers(3, 900)), 50 + k)
+        first_name = hs[0][0] + b":"
+
+        def sig_of(raw):
+            return raw[:raw.find(first_name)]
+        good_raw, _ = sign_email(hs, body, k0, SignSpec(header_canon=["relaxed", "simple"][int(rng.integers(0, 2))],
+                                                        body_canon=["relaxed", "simple"][int(rng.integers(0, 2))]))
+        msg = good_raw[len(sig_of(good_raw)):]
+        sigs = [] if rng.random() < 0.15 else [sig_of(good_raw)]
+        for j in range(int(rng.integers(0, 7))):
+            kind = int(rng.integers(0, 7))
+            if kind == 0:
+                x = sig_of(sign_email(hs, body, k1, SignSpec(domain="other.org", selector=f"o{j}"))[0])
+            elif kind == 1:
+                x = sig_of(sign_email(hs, cases._body(100 + j, 900 + j), k0, SignSpec(selector=f"old{j}"))[0])
+            elif kind == 2:
+                x = bytearray(sig_of(sign_email(hs, body, k0, SignSpec(selector=f"flip{j}", fold_sig=False))[0]))
+                at = x.rfind(b"b=") + 10
+                x[at] = ord("A") if x[at] != ord("A") else ord("B")
+                x = bytes(x)
+            elif kind == 3:
+                x = sig_of(sign_email(hs, body, k1, SignSpec(selector=f"wrongkey{j}"))[0])          # d=example.com, another key
+            elif kind == 4:
+                x = b"DKIM-Signature: v=1; a=rsa-sha256; d=example.com; s=broken%d\r\n" % j
+            elif kind == 5:
+                x = sig_of(sign_email(hs, body, ed, SignSpec(selector=f"ed{j}"))[0])
+            else:
+                x = sig_of(sign_email(hs, body, k0, SignSpec(selector=f"again{j}", signed=("from", "subject")))[0])   # a second good one
+            sigs.append(x)
+        order = rng.permutation(len(sigs))
+        lines = msg.split(b"\r\n\r\n", 1)
+        hdr_lines = lines[0].split(b"\r\n")
+        hdr_fields, cur = [], b""
+        for ln in hdr_lines:                                   # re-join folded header fields
+            if ln[:1] in (b" ", b"\t"):
+                cur += b"\r\n" + ln
+            else:
+                if cur:
+                    hdr_fields.append(cur)
+                cur = ln
+        hdr_fields.append(cur)
+        for ix in order:                                       # each signature header at the top or somewhere among the fields
+            pos = 0 if rng.random() < 0.6 else int(rng.integers(0, len(hdr_fields) + 1))
+            hdr_fields.insert(pos, sigs[int(ix)].rstrip(b"\r\n"))
+        raw = b"\r\n".join(hdr_fields) + b"\r\n\r\n" + lines[1]
+        emails.append(A.Email("example.com", raw, A.PublicKey(k0.pkcs1_der)))
+    got, exp, d1, d2 = run_both(engine, oracle, emails)
+    assert_records_equal(got, exp, None, "signature lists")
+    st = np.asarray(exp["status"])
+    assert (st == A.ZKE_OK).sum() > 60 and (st != A.ZKE_OK).sum() > 15
+    assert len({int(x) for x in exp["sig_index"]}) >= 4
+
+
 @pytest.mark.parametrize("seed", [5, 6])
 def test_key_and_domain_mutation_fuzz_parity(engine, oracle, seed):
     """The other two inputs of an Email: the DER of the key (lengths, tags, truncations, trailing bytes, anywhere in the
