@@ -139,6 +139,39 @@ def test_mutation_fuzz_parity(engine, oracle, seed):
     assert_records_equal(got, exp, None, "fuzz")
 
 
+@pytest.mark.parametrize("seed", [51])
+def test_length_tag_fuzz_parity(engine, oracle, seed):
+    """l= over random body lengths, both body canonicalisations and every relation to the canonical length (0, inside, the
+    exact length, beyond it, 2^32 and 2^64 neighbours, twenty digits, a sign, blanks): the hashed prefix, the length class
+    the hash stage files it under, canon_body_len and the verdict are the oracle's."""
+    from synth import SignSpec, sign_email
+    rng = np.random.default_rng(seed)
+    k0 = cases.K("rsa2048_00")
+    emails = []
+    for k in range(320):
+        n = int(rng.integers(3, 3000)) if k % 9 else int(rng.integers(3, 70000))
+        hs, body = cases._hdrs(300 + k), cases._body(n, 300 + k)
+        bc = ["relaxed", "simple"][int(rng.integers(0, 2))]
+        r = rng.random()
+        if r < 0.5:
+            L = int(rng.integers(0, n + 3))
+        elif r < 0.6:
+            L = n + int(rng.integers(0, 100))
+        elif r < 0.7:
+            L = [0, 1, 63, 64, 65, 55, 56, 119, 120][int(rng.integers(0, 9))]
+        else:
+            L = None
+        extra = ""
+        if r >= 0.7 and r < 0.9:                               # an l= the signer did not honour (bh covers the whole body), signed as written
+            extra = "l=" + ["4294967296", "4294967295", "18446744073709551616", "18446744073709551615", "99999999999999999999",
+                            "-1", "+5", " 12 ", "0x10", "", "1 2", "00000000000000000000012", str(n + 5), "9" * 40][int(rng.integers(0, 14))] + "; "
+        raw, _ = sign_email(hs, body, k0, SignSpec(body_canon=bc, length=L, extra_tags=extra))
+        emails.append(A.Email("example.com", raw, A.PublicKey(k0.pkcs1_der)))
+    got, exp, d1, d2 = run_both(engine, oracle, emails)
+    assert_records_equal(got, exp, None, "l= fuzz")
+    assert len({(int(a), int(b)) for a, b in zip(exp["status"], exp["detail"])}) >= 3
+
+
 @pytest.mark.parametrize("seed", [41, 42])
 def test_signature_list_fuzz_parity(engine, oracle, seed):
     """Up to seven DKIM-Signature headers per message, in random file order and at random places of the header block: the good
