@@ -39,6 +39,13 @@ sv = D.ShardedVerifier(orc, rank=rank, world=world)
 assert sv.load(wl.emails) == (lo, hi) and sv.bounds == bounds
 w2 = sv.verify()
 assert w2.tobytes() == D.witness_of(full).tobytes(), "ShardedVerifier: witnesses differ from the single-process batch"
+# fewer e-mails than ranks (one rank's range is empty), and none at all: every rank still takes part in the gather
+for few in (wl.emails[:1], wl.emails[5:6], []):
+    lo1, hi1 = sv.load(few)
+    w3 = sv.verify()
+    want = D.witness_of(orc.verify_batch(A.PackedBatch(few))) if few else np.zeros(0, A.WITNESS_DTYPE)
+    assert len(w3) == len(few) and w3.tobytes() == want.tobytes(), ("short batch", len(few), rank)
+sv.load(wl.emails)
 my_bytes = sum(sizes[lo:hi])
 tot = torch.tensor([my_bytes], dtype=torch.int64)
 dist.all_reduce(tot)

@@ -167,6 +167,11 @@ class ShardedVerifier:
         """Verify this rank's range and exchange the witnesses.  Returns the WHOLE batch's witnesses in batch order:
         a torch uint8 tensor of ``n_total * 72`` bytes on the device (product path) or a numpy WITNESS_DTYPE array (CPU tier)."""
         counts = [self.bounds[r + 1] - self.bounds[r] for r in range(self.world)]
+        if self.n_total == 0:                    # every rank knows it: nothing to verify, nothing to exchange
+            if not self.on_device:
+                return np.zeros(0, WITNESS_DTYPE)
+            import torch
+            return torch.zeros(0, dtype=torch.uint8, device=self.device)
         if not self.on_device:
             local = self.engine.verify_batch(self._local) if self._local is not None else np.zeros(0, RESULT_DTYPE)
             if self.world == 1:
