@@ -151,3 +151,36 @@ def test_config2_shape_ed25519(engine):
     got2 = engine.verify_batch(A.PackedBatch(emails))
     changed = [k for k in range(1024) if got2[k].tobytes() != got[k].tobytes()]
     assert changed == [77] and int(got2[77]["status"]) == A.ZKE_DKIM_NOT_PASS and int(got2[77]["detail"]) == A.D_SIG_MISMATCH
+
+
+def test_one_batch_larger_than_4_gib(oracle):
+    """Maximum sizes: ONE batch of 70 e-mails of 64 MB — 4.7 GB of raw e-mails, so every offset that is relative to the batch
+    (scratch slots at 2 x the raw offset, the packed image, the staging copy) passes 2^32 inside it; bodies of a million
+    SHA-256 blocks each; simple and relaxed body canonicalisation; one e-mail with a flipped bit far into its body.  Host
+    entry (pinned image, one H2D of 4.7 GB), records against the oracle's."""
+    import zkemail_rs_amd as z
+    from synth import SignSpec, sign_email
+    import cases
+    k0 = cases.K()
+    blk = cases._body(1 << 20, 7)
+    emails = []
+    for i in range(70):
+        body = (b"mail %d\r\n" % i) + blk * 64
+        raw, _ = sign_email(cases._hdrs(400 + i), body, k0, SignSpec(body_canon="relaxed" if i % 23 == 5 else "simple"))
+        if i == 41:
+            raw = bytearray(raw); raw[len(raw) - (40 << 20)] ^= 0x20; raw = bytes(raw)
+        emails.append(A.Email("example.com", raw, A.PublicKey(k0.pkcs1_der)))
+    p = A.PackedBatch(emails)
+    del emails
+    assert int(p.raw_off[-1]) > (1 << 32) + (1 << 28)
+    exp = oracle.verify_batch(p, threads=8)
+    eng = z.Engine(slots=1)
+    try:
+        got = eng.verify_batch(p)
+    finally:
+        eng.close()
+    for f in A.RESULT_DTYPE.names:
+        if f != "reserved":
+            assert (np.asarray(got[f]) == np.asarray(exp[f])).all(), f
+    st = [int(x) for x in got["status"]]
+    assert st.count(A.ZKE_OK) == 69 and st[41] == A.ZKE_DKIM_NOT_PASS and int(got[41]["detail"]) == A.D_BODY_HASH_MISMATCH

@@ -621,3 +621,54 @@ def test_body_clean_prefix_edges(engine, oracle):
         assert int(d1.full_len[i]) == bl == len(it["canon_body"]), names[i]
         assert bytes(d1.canon_body[i, :bl]) == it["canon_body"], names[i]
         assert bytes(got[i]["body_hash"]) == it["body_hash"], names[i]
+
+
+def test_device_entry_offsets_beyond_4_gib():
+    """The CSR offsets are absolute and 64 bits wide: a range of a blob larger than 4 GiB (BASELINE configs[3] in one piece is
+    4.4 GB of raw e-mails; ShardedVerifier hands the engine chunks of such a blob) must verify exactly like the same e-mails at
+    offset 0.  Raw, domain and key blobs each sit behind 4 GiB + an odd number of bytes of other data; with and without regex
+    parts (canonical headers, cleaned bodies and captures are addressed through the same offsets)."""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent(f"""
+        import sys
+        sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r})
+        import numpy as np, torch
+        torch.zeros(1, device="cuda")
+        import bench, zkemail_rs_amd as z
+        from zkemail_rs_amd import _abi as A
+        import synth
+        from test_gpu_verify import assert_records_equal
+        engine = z.Engine(0)
+        dev = torch.device("cuda", 0)
+        inputs, wl, _ = synth.make_regex_workload("far", 70, 3000, n_header_parts=1, n_body_parts=1, qp_frac=0.05, fail_frac=0.2, seed=23)
+        BASES = {{"raw": (1 << 32) + (3 << 20) + 12345, "dom": (1 << 32) + 77, "key": (1 << 32) + (1 << 31) + 5}}
+        for with_regex in (False, True):
+            packed = engine.pack_with_regex(inputs) if with_regex else A.PackedBatch(wl.emails)
+            host = engine.verify_batch(packed)
+            cb, keep, totals = bench.device_batch(torch, packed, dev)
+            far = {{}}
+            for name, blob, off, field_blob, field_off in (("raw", packed.raw_blob, packed.raw_off, "raw_blob", "raw_off"),
+                                                          ("dom", packed.domain_blob, packed.domain_off, "domain_blob", "domain_off"),
+                                                          ("key", packed.key_blob, packed.key_off, "key_blob", "key_off")):
+                base = BASES[name]
+                big = torch.empty(base + len(blob) + 64, dtype=torch.uint8, device=dev)
+                big[base - 4096:base] = 0xA5                                   # what lies in front of the range is not zeros
+                big[base:base + len(blob)] = torch.from_numpy(np.ascontiguousarray(blob).copy()).to(dev)
+                o = torch.from_numpy((np.asarray(off, dtype=np.uint64) + np.uint64(base)).view(np.uint8).copy()).to(dev)
+                far[name] = (big, o)
+                setattr(cb, field_blob, big.data_ptr()); setattr(cb, field_off, o.data_ptr())
+            out = torch.zeros(packed.n * 192, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            engine.verify_batch_device(cb, totals[0], totals[1], totals[2], out.data_ptr(), 0)
+            engine.sync()
+            got = out.cpu().numpy().view(A.RESULT_DTYPE)
+            assert_records_equal(got, host, None, f"offsets beyond 4 GiB, with_regex={{with_regex}}")
+            assert (np.asarray(host["status"]) == 0).sum() > 20
+            del far, out
+            torch.cuda.empty_cache()
+        engine.close()
+        print("far ok")
+    """)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "far ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
