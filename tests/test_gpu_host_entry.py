@@ -64,8 +64,8 @@ def test_async_host_entry_through_slots(oracle):
 
 
 def test_four_threads_one_engine_records_identical_to_serial():
-    """4 host threads x 50 batches on one engine with 3 slots (so threads share slots), host and device entry mixed: every
-    record identical to a serial run.  (A subprocess: torch must initialise the GPU before the engine does in a process that
+    """4 host threads x 50 batches on one engine with 3 slots (so threads share slots), host and device entry and regex batches
+    mixed: every record identical to a serial run.  (A subprocess: torch must initialise the GPU before the engine does in a process that
     uses both.)"""
     import os, subprocess, sys, textwrap
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -74,7 +74,7 @@ def test_four_threads_one_engine_records_identical_to_serial():
         sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r})
         import numpy as np, torch
         torch.zeros(1, device="cuda")
-        import bench, oracle_lib, zkemail_rs_amd as z
+        import bench, oracle_lib, synth, zkemail_rs_amd as z
         from zkemail_rs_amd import _abi as A
         from test_gpu_host_entry import _batches
         from test_gpu_verify import assert_records_equal
@@ -84,6 +84,13 @@ def test_four_threads_one_engine_records_identical_to_serial():
         serial = [eng.verify_batch(p).copy() for p, _ in bs]
         for (p, _), s in zip(bs, serial):
             assert_records_equal(s, oracle.verify_batch(p, threads=4), None, "serial run")
+        # regex batches too (the registry's read path and the slots' regex workspaces under the same traffic)
+        rx = []
+        for k in range(3):
+            inputs, _, _ = synth.make_regex_workload("thr", 40 + 9 * k, 2000, n_header_parts=1 + k % 2, n_body_parts=k % 2, qp_frac=0.05, fail_frac=0.2, seed=450 + k)
+            rx.append(eng.pack_with_regex(inputs))
+            assert_records_equal(eng.verify_batch(rx[-1]), oracle.verify_batch(oracle.pack_with_regex(inputs), threads=4), None, "serial regex run")
+        rx_serial = [eng.verify_batch(p).copy() for p in rx]
         dev = torch.device("cuda", 0)
         dbs = [bench.device_batch(torch, p, dev) for p, _ in bs]
         errors = []
@@ -94,6 +101,13 @@ def test_four_threads_one_engine_records_identical_to_serial():
                 for it in range(50):
                     k = (tid + it) % len(bs)
                     p = bs[k][0]
+                    if it % 5 == 4:                     # a regex batch through the host entry
+                        r = (tid + it) % len(rx)
+                        got = eng.verify_batch(rx[r])
+                        for f in A.RESULT_DTYPE.names:
+                            if f != "reserved" and not (np.asarray(got[f]) == np.asarray(rx_serial[r][f])).all():
+                                raise AssertionError(f"thread {{tid}} iteration {{it}}: regex batch, field {{f}} differs from the serial run")
+                        continue
                     if it % 3 == 2:                     # the device-resident entry from the same thread
                         cb, keep, totals = dbs[k]
                         outs_dev[k].zero_()
