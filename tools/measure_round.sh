@@ -27,6 +27,12 @@ prof() {   # prof NAME bench-args...: kernel summary
   cp $out/p_$name/run_kernel_stats.csv $out/${name}_kernel_stats.csv
   head -8 $out/${name}_kernel_stats.csv | cut -c1-220
 }
+pmci_named() {   # like pmci, the counter list taken from the caller's PMC_I, the summary named NAME_pmc.json
+  local name=$1; shift
+  rm -rf $out/pi_$name
+  rocprofv3 --pmc $PMC_I -d $out/pi_$name -o runc --output-format csv -- python bench.py $B "$@" > $out/pi_$name.log 2>&1 || { tail -5 $out/pi_$name.log; return 1; }
+  python tools/pmc_summary.py $out/pi_$name > $out/${name}_pmc.json; cat $out/${name}_pmc.json
+}
 pmci() {   # pmci NAME bench-args...: instruction counters, per kernel and launch
   local name=$1; shift
   rm -rf $out/pi_$name
@@ -34,6 +40,11 @@ pmci() {   # pmci NAME bench-args...: instruction counters, per kernel and launc
   python tools/pmc_summary.py $out/pi_$name > $out/${name}_instr_pmc.json; cat $out/${name}_instr_pmc.json
 }
 for part in "$@"; do case $part in
+stalls)   # where a wave's cycles go, per kernel: parked (s_waitcnt / barrier), issue-stalled, issuing — the guide's disjoint split of SQ_WAVE_CYCLES
+  for W in c2 c5re; do
+    PMC_I="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS" pmci_named stalls_$W --workload $W --steps 6 --warmup 3 --streams 1 --alone-steps 0 || exit 1
+  done
+  ;;
 lines)
   timeout -k 10 500 python bench.py > $out/bench_line.json 2> $out/bench_line.err || { tail -20 $out/bench_line.err; exit 1; }
   line $out/bench_line.json default
