@@ -380,12 +380,20 @@ def main():
     # launches of a batch) x 3.9 cycles per instruction and SIMD (measured: profiles/r01_ubench_valu_rate.txt) on 1 024 SIMDs
     # at 2.4 GHz is the time the chip needs to ISSUE one batch, whatever overlaps with whatever.
     issue = None
+    # The scalar side (profiles/r03_ubench_coissue.txt): a SIMD gets one SALU instruction per 4.06 cycles and issues it BESIDE
+    # another wave's vector instruction, so the bound is the larger of the two streams, not their sum.  (3.9 is the rate of the
+    # three-operand opcodes the hash and modexp code is made of; two-operand opcodes issue in 2.2 — for a front-end-heavy
+    # workload the true floor lies below this figure, and frac_of_issue_bound flatters by that much.)
     if prof.get("valu_per_batch"):
-        issue_us = prof["valu_per_batch"] * 3.9 / (1024 * 2400.0)
+        valu_us = prof["valu_per_batch"] * 3.9 / (1024 * 2400.0)
+        salu_us = (prof.get("salu_per_batch") or 0) * 4.06 / (1024 * 2400.0)
+        issue_us = max(valu_us, salu_us)
         issue = {"issue_bound_us_per_step": round(issue_us, 2), "frac_of_issue_bound": round(issue_us / (step_s * 1e6), 4),
+                 "valu_us_per_step": round(valu_us, 2), "salu_us_per_step": round(salu_us, 2),
                  "valu_wave_instr_per_batch": prof["valu_per_batch"], "salu_wave_instr_per_batch": prof.get("salu_per_batch"),
                  "source": prof["instr_source"],
-                 "how": "VALU wave-instructions per batch (PMC) x 3.9 cycles / (1024 SIMDs x 2.4 GHz); frac = that / measured us per step"}
+                 "how": "max(VALU wave-instructions per batch x 3.9 cycles, SALU x 4.06 cycles) / (1024 SIMDs x 2.4 GHz) (PMC counts; "
+                        "rates: profiles/r01_ubench_valu_rate.txt, r03_ubench_coissue.txt); frac = that / measured us per step"}
     def per_launch(t, how):
         if not t:
             return None
