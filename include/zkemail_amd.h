@@ -460,6 +460,9 @@ int zke_abi_encode(const uint8_t* from_domain_hash /*[32]*/, const uint8_t* publ
 /* Library / build identification.  zke_abi_version() = 3 for this header (struct layouts and entry points of ABI 0.3). */
 const char* zke_version(void);
 uint32_t zke_abi_version(void);
+/* The reference panic site a status stands for, as text ("assert!(verified)  core/src/circuits.rs:13"); "" for ZKE_OK,
+ * "unknown status" beyond the enum.  A static string. */
+const char* zke_status_name(uint32_t status);
 /* 1 if a HIP device is usable from this process, else 0 (never falls back to a CPU path). */
 int zke_device_available(void);
 

@@ -286,6 +286,23 @@ extern "C" {
 const char* zke_version(void) { return "zkemail.rs_amd 0.3 (gfx950)"; }
 uint32_t zke_abi_version(void) { return 3; }
 
+const char* zke_status_name(uint32_t status) {
+  static const char* const names[] = {
+      "",
+      "mailparse::parse_mail(..).unwrap()  core/src/email.rs:26",
+      "DkimPublicKey::try_from_bytes(..).unwrap()  core/src/email.rs:29",
+      "verify_email_with_key(..).unwrap()  core/src/email.rs:33",
+      "assert!(verified)  core/src/circuits.rs:13",
+      ".expect(\"Value cannot be null\")  core/src/circuits.rs:24",
+      "canonicalize_signed_email(..).unwrap()  core/src/circuits.rs:35",
+      "dense::DFA::from_bytes(..).unwrap()  core/src/regex.rs:32-33",
+      "assert!(verified) on header parts  core/src/circuits.rs:45",
+      "assert!(verified) on body parts  core/src/circuits.rs:54",
+      "input outside what this engine implements (ZKE_UNSUPPORTED; detail says which limit)",
+  };
+  return status < sizeof names / sizeof names[0] ? names[status] : "unknown status";
+}
+
 // ---- Solidity ABI encoding of the outputs (core/src/io.rs:5-53; alloy-sol-types' SolValue::abi_encode = abi.encode(value)).
 // The struct is a dynamic type: 32-byte offset 0x20, then the tuple's head / tail.  A string[] is its length, one offset
 // per element (relative to the start of the offsets), then each string as length + bytes padded to 32.

@@ -128,7 +128,7 @@ EXPORTED_SYMBOLS = [
     "zke_ed25519_verify_batch", "zke_engine_reserve", "zke_get_slot_timings", "zke_verify_email_with_regex",
     "zke_abi_encode", "zke_engine_join", "zke_verify_batch_async", "zke_batch_wait", "zke_dfa_status", "zke_dfa_unregister",
     "zke_process_init", "zke_abi_version", "zke_engine_reserve_host", "zke_wire_decode", "zke_wire_free", "zke_wire_view",
-    "zke_wire_external_input", "zke_verify_wire", "zke_shard_bounds",
+    "zke_wire_external_input", "zke_verify_wire", "zke_shard_bounds", "zke_status_name",
 ]
 
 
