@@ -5,6 +5,7 @@
 #   satprof    the chip-filling SHA-256 launches: kernel summary + PMC
 #   wlprof     c4shard, c3, c5re, c2ragged: kernel summary + instruction PMC each (dfa / qp / canon kernels get a duration and a count)
 #   workloads  every workload's line once
+#   stalls     SQ_WAVE_CYCLES split into parked / issue-stalled / issuing per kernel (c2, c5re)
 # Every file a figure in README / DESIGN / the bench line cites is copied from there into profiles/ by hand (named r03_*).
 set -o pipefail
 out=gpurun_out/r03; mkdir -p $out
