@@ -60,8 +60,11 @@ def test_c_example_verifies_the_rfc8463_message(tmp_path):
     fd, pk = hashlib.sha256(meta["from_domain"].encode()).digest(), hashlib.sha256(key).digest()
     assert f"from_domain_hash {fd.hex()}" in r.stdout and f"public_key_hash  {pk.hex()}" in r.stdout
     assert "abi_encode       " + E.abi_encode(A.EmailVerifierOutput(fd, pk, [])).hex() in r.stdout
+    # one body byte changed, in the message with the Ed25519 signature only (beside the RSA signature of the original an Ed25519
+    # key is "a= and key type disagree", an input the engine reports as unsupported instead)
+    from test_rfc8463_vector import without_signature
     bad = tmp_path / "bad.eml"
-    raw = bytearray(open(eml, "rb").read()); raw[-5] ^= 1
+    raw = bytearray(without_signature(open(eml, "rb").read(), 1)); raw[-5] ^= 1
     bad.write_bytes(bytes(raw))
     r2 = subprocess.run([str(exe), str(bad), meta["from_domain"], "ed25519", key.hex()], capture_output=True, text=True, timeout=300)
     assert r2.returncode == 1 and "core/src/circuits.rs:13" in r2.stdout, r2.stdout + r2.stderr
