@@ -927,10 +927,16 @@ __device__ __forceinline__ uint32_t decode_rsa_key(const Str& k, RsaJob* J, uint
   for (uint32_t i = 0; i < el; i++) e = (e << 8) | at(k, w, ep + i);
   if (e < 2 || e > ((1ull << 33) - 1)) return ZKE_D_KEY_RANGE;
   // modulus, big-endian, right-aligned in the 512-byte field (zero fill in front)
-  for (uint32_t o = lane_id(); o < 512; o += 64) {
-    uint8_t b = 0;
-    if (o >= 512 - nl) b = (uint8_t)ldb(k, np + (o - (512 - nl)));
-    J->mod[o] = b;
+  {
+    // (the eight loads of a lane leave together; interleaved with the stores each waited for its own round trip)
+    uint8_t mb[8];
+#pragma unroll
+    for (uint32_t t = 0; t < 8; t++) {
+      const uint32_t o = (uint32_t)lane_id() + 64 * t;
+      mb[t] = o >= 512 - nl ? (uint8_t)ldb(k, np + (o - (512 - nl))) : (uint8_t)0;
+    }
+#pragma unroll
+    for (uint32_t t = 0; t < 8; t++) J->mod[(uint32_t)lane_id() + 64 * t] = mb[t];
   }
   even = !(at(k, w, np + nl - 1) & 1) && bits != 0;
   if (lane_id() == 0) { J->e = e; J->k = nl; J->bits = bits; }
@@ -954,9 +960,14 @@ __device__ __forceinline__ uint32_t rsa_route(const Str& k, uint32_t np, uint32_
   };
   const uint32_t l0 = limb(lane), l1 = limb(64 + lane);
   const KeyCacheEntry* E = cache + key_cache_slot(__builtin_amdgcn_readfirstlane(l0), __builtin_amdgcn_readlane(l0, 1));
-  if (ld_agent(&E->state) != 2u) return 0x200;                      // not cached (yet)
-  if (ld_agent(&E->bits) != bits) return 0x400;                     // the slot belongs to another key
-  const bool same = ld_agent(&E->mod[lane]) == l0 && ld_agent(&E->mod[64 + lane]) == l1;
+  // All four loads leave before the first answer is looked at: each is an agent-scope load served at the coherence point, a
+  // round trip of a microsecond or more, and three of them in a row (state, then bits, then the limbs) were a twentieth of the
+  // wave's life.  An entry is written once and immutable from state == 2 on (rsa_kernel.hip.h): limbs served before the
+  // publication beside a state served after it can only turn a hit into a miss — the wave routine then takes the signature.
+  const uint32_t st = ld_agent(&E->state), eb = ld_agent(&E->bits), m0 = ld_agent(&E->mod[lane]), m1 = ld_agent(&E->mod[64 + lane]);
+  if (st != 2u) return 0x200;                                       // not cached (yet)
+  if (eb != bits) return 0x400;                                     // the slot belongs to another key
+  const bool same = m0 == l0 && m1 == l1;
   return __ballot(!same) == 0 ? (bits <= 2048 ? (uint32_t)RSA_F_QUAD : (uint32_t)RSA_F_OCT) : 0x400u;
 }
 

@@ -16,11 +16,18 @@ namespace zke {
 // The entry is immutable once state == 2, and the state load is waited for before the other loads issue.
 template <int NL>
 __device__ __forceinline__ bool key_cache_hit(const KeyCacheEntry* E, const Big<NL>& nn, uint32_t bits) {
-  if (ld_agent(&E->state) != 2u || ld_agent(&E->bits) != bits) return false;
+  // Every load issued before the first is looked at: one round trip to the coherence point instead of three (see rsa_route).
+  // Limbs served before the entry's publication and a state served after it can only turn a hit into a miss (an unpublished
+  // entry does not hold this modulus), never the reverse: an entry is written once and immutable from state == 2 on.
   const int lane = threadIdx.x & 63;
+  const uint32_t st = ld_agent(&E->state), eb = ld_agent(&E->bits);
+  uint32_t m[NL];
+#pragma unroll
+  for (int q = 0; q < NL; q++) m[q] = ld_agent(&E->mod[q * 64 + lane]);
+  if (st != 2u || eb != bits) return false;
   bool same = true;
 #pragma unroll
-  for (int q = 0; q < NL; q++) same = same && ld_agent(&E->mod[q * 64 + lane]) == nn.v[q];
+  for (int q = 0; q < NL; q++) same = same && m[q] == nn.v[q];
   return ballot64(!same) == 0;
 }
 
@@ -89,6 +96,8 @@ __device__ __forceinline__ bool rsa_wave(const RsaJob* __restrict__ jobs, uint32
     if (cache) {
       E = cache + key_cache_slot(n0, n1);
       if (key_cache_hit<NL>(E, nn, bits)) {
+        // (only now: the constants are valid once state == 2 has been SEEN — loads issued beside the probe could be served
+        // before the publication and the state after it)
 #pragma unroll
         for (int q = 0; q < NL; q++) rr.v[q] = ld_agent(&E->rr[q * 64 + lane]);
         ninv = ld_agent(&E->ninv);
