@@ -284,12 +284,24 @@ impl Engine {
         if emails.is_empty() {
             return Ok(Vec::new());
         }
-        let packed = Packed::from_emails(emails.iter());
-        let batch = packed.batch(emails.len());
+        // The e-mails stay where they are: one zke_email_ref per `Email`, pointing into its own Vec<u8> / Strings.  The engine
+        // gathers them into its pinned staging image on its packing threads (zke_verify_emails) — no concatenation here.
+        let refs: Vec<sys::zke_email_ref> = emails
+            .iter()
+            .map(|e| sys::zke_email_ref {
+                raw: e.raw_email.as_ptr(),
+                raw_len: e.raw_email.len(),
+                from_domain: e.from_domain.as_ptr() as *const std::os::raw::c_char,
+                domain_len: e.from_domain.len(),
+                key: e.public_key.key.as_ptr(),
+                key_len: e.public_key.key.len(),
+                key_type: key_type_code(&e.public_key.key_type) as u32,
+                external_input_null: e.external_inputs.iter().any(|x| x.value.is_none()) as u32,
+            })
+            .collect();
         let mut out = vec![zeroed_result(); emails.len()];
-        // SAFETY: every pointer in `batch` refers into `packed`, which lives until the call returns (the entry point is
-        // synchronous); `out` holds n records.
-        let rc = unsafe { sys::zke_verify_batch(self.raw, &batch, out.as_mut_ptr(), ptr::null_mut()) };
+        // SAFETY: every pointer in `refs` refers into `emails`, borrowed for the whole (synchronous) call; `out` holds n records.
+        let rc = unsafe { sys::zke_verify_emails(self.raw, refs.as_ptr(), refs.len() as u32, out.as_mut_ptr()) };
         if rc != 0 {
             return Err(self.last_error(rc));
         }

@@ -334,6 +334,22 @@ int zke_verify_batch(zke_engine* e, const zke_batch* in, zke_result* out, zke_de
 int zke_verify_batch_async(zke_engine* e, const zke_batch* in, zke_result* out, uint64_t* ticket);
 int zke_batch_wait(zke_engine* e, uint64_t ticket);
 
+/* The reference's own layout: n separate Email values, each with buffers of its own (`&[Email]`: a Vec<u8> and two Strings per
+ * e-mail, core/src/structs.rs:49-54) instead of three concatenated blobs.  The engine gathers them straight into its pinned
+ * staging image on its packing threads — ONE copy between the caller's Vecs and the DMA engine — and computes the CSR offsets
+ * itself; a caller that would only concatenate the buffers to call zke_verify_batch saves that pass (a single-threaded copy of
+ * the whole batch).  Same pipeline, same records, same ticket protocol as zke_verify_batch_async; verify_email only (regex
+ * batches carry per-e-mail capture tables: zke_batch). */
+typedef struct zke_email_ref {
+  const uint8_t* raw;         size_t raw_len;        /* Email.raw_email */
+  const char*    from_domain; size_t domain_len;     /* Email.from_domain (UTF-8, no terminator needed) */
+  const uint8_t* key;         size_t key_len;        /* Email.public_key.key */
+  uint32_t key_type;                                 /* ZKE_KEY_* of Email.public_key.key_type */
+  uint32_t external_input_null;                      /* != 0: some ExternalInput.value is None (circuits.rs:24) */
+} zke_email_ref;
+int zke_verify_emails(zke_engine* e, const zke_email_ref* emails, uint32_t n, zke_result* out);
+int zke_verify_emails_async(zke_engine* e, const zke_email_ref* emails, uint32_t n, zke_result* out, uint64_t* ticket);
+
 /* Device-resident batch: every pointer in `in` and `out_dev` is device memory (the part-id lists stay host arrays);
  * `raw_total`, `domain_total`, `key_total` are the blob sizes (the CSR tails), which the
  * host needs for workspace sizing without a device read.  Takes the engine's next submission slot (round-robin),

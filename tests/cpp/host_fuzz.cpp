@@ -107,6 +107,28 @@ int main(int argc, char** argv) {
     for (auto& t : ths) t.join();
     if (bad) { fprintf(stderr, "CopyPool: %d copies differ from memcpy\n", bad.load()); return 1; }
     cases += 240;
+    // gather: thousands of small pieces with consecutive destinations (zke_verify_emails), from two callers at once
+    std::vector<std::thread> th2;
+    for (int t = 0; t < 2; t++) th2.emplace_back([&, t] {
+      std::mt19937_64 r(7 + t);
+      for (int it = 0; it < 12; it++) {
+        const size_t np = (size_t)(r() % 3000) + 1;
+        std::vector<std::vector<uint8_t>> srcs(np);
+        std::vector<CopyPool::Piece> pc(np);
+        size_t total = 0;
+        for (auto& v : srcs) { v.resize((size_t)(r() % 5 == 0 ? r() % 20000 : r() % 600)); for (size_t i = 0; i < v.size(); i += 31) v[i] = (uint8_t)r(); total += v.size(); }
+        std::vector<uint8_t> dst(total + 64, 0xEE), ref(total + 64, 0xEE);
+        size_t o = r() % 64 == 0 ? 0 : r() % 48;
+        for (size_t i = 0; i < np; i++) { pc[i] = CopyPool::Piece{dst.data() + o, srcs[i].empty() ? nullptr : srcs[i].data(), srcs[i].size()}; if (!srcs[i].empty()) memcpy(ref.data() + o, srcs[i].data(), srcs[i].size()); o += srcs[i].size(); if (o > total + 16) break; }
+        if (o > total + 48) continue;
+        dst.resize(std::max(dst.size(), o)); ref.resize(dst.size(), 0xEE);
+        pool.gather(pc.data(), np);
+        if (dst != ref) bad++;
+      }
+    });
+    for (auto& t : th2) t.join();
+    if (bad) { fprintf(stderr, "CopyPool::gather: %d results differ from memcpy\n", bad.load()); return 1; }
+    cases += 24;
   }
   // ---- zke_abi_encode: string tables of random sizes into heap buffers of exactly the size asked for, one byte less, and none
   for (int it = 0; it < 3000; it++) {

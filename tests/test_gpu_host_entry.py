@@ -229,3 +229,56 @@ def test_host_offsets_are_checked(oracle):
         assert_records_equal(eng.verify_batch(p), good, None, "after the refused batches")
     finally:
         eng.close()
+
+
+def test_scattered_emails_entry_equals_the_packed_one(oracle):
+    """zke_verify_emails / _async: the e-mails handed over one by one, each in buffers of its own (what `&[Email]` is in the
+    reference), gathered by the engine into its staging image — records identical to zke_verify_batch over the concatenated
+    blobs, for ragged batches with invalid and empty e-mails, n = 0 / 1 / 700, through slot reuse and from two threads."""
+    import zkemail_rs_amd as z
+    eng = z.Engine(slots=3, host_threads=3)
+    try:
+        assert len(eng.verify_emails([])) == 0
+        shapes = _batches(3, n=90, seed0=700) + _batches(1, n=700, seed0=710) + _batches(1, n=1, seed0=720)
+        lists = []
+        for p, wl in shapes:
+            ems = list(wl.emails)
+            if len(ems) > 5:      # an empty e-mail, an empty domain and an empty key in the middle of the gather
+                ems[3] = A.Email("example.com", b"", ems[3].public_key)
+                ems[4] = A.Email("", ems[4].raw_email, ems[4].public_key)
+                ems[5] = A.Email("example.com", ems[5].raw_email, A.PublicKey(b"", "rsa"))
+            lists.append(ems)
+        want = [eng.verify_batch(A.PackedBatch(ems)) for ems in lists]
+        for ems, w in zip(lists, want):
+            assert_records_equal(w, oracle.verify_batch(A.PackedBatch(ems), threads=4), None, "packed entry")
+            assert_records_equal(eng.verify_emails(ems), w, None, f"scattered entry, n={len(ems)}")
+        # asynchronous, more batches than slots, waited for out of order
+        refs = [A.EmailRefs(ems) for ems in lists]
+        pend = [eng.verify_emails_async(refs[k % len(refs)]) for k in range(8)]
+        for k in (7, 0, 3, 1, 2, 6, 5, 4):
+            eng.wait(pend[k][0])
+            assert_records_equal(pend[k][1], want[k % len(refs)], None, f"async scattered batch {k}")
+        errors = []
+
+        def worker(tid):
+            try:
+                for it in range(30):
+                    k = (tid + it) % len(lists)
+                    got = eng.verify_emails(refs[k]) if it % 2 else eng.verify_batch(A.PackedBatch(lists[k]))
+                    assert_records_equal(got, want[k], None, f"thread {tid} iteration {it}")
+            except Exception as ex:
+                errors.append(repr(ex))
+        ths = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join(timeout=300)
+        assert not errors, errors[:2]
+        # a null buffer with a length is refused, and the engine stays usable
+        bad = A.EmailRefs(lists[0][:4])
+        bad.arr[2].raw = None
+        with pytest.raises(z.EngineError, match="null buffer"):
+            eng.verify_emails(bad)
+        assert_records_equal(eng.verify_emails(refs[0]), want[0], None, "after the refused call")
+    finally:
+        eng.close()

@@ -155,6 +155,32 @@ STRICT_FLAGS = ("enforce_expiry_x", "canon_takes_verified_signature", "canon_ign
                 "b_removes_own_span_only")          # zke_options' strictness flags, in ZKE_STRICT_* bit order
 
 
+class zke_email_ref(C.Structure):
+    """One Email with buffers of its own (zke_verify_emails): what `&[Email]` holds in the reference."""
+    _fields_ = [
+        ("raw", C.c_void_p), ("raw_len", C.c_size_t), ("from_domain", C.c_void_p), ("domain_len", C.c_size_t),
+        ("key", C.c_void_p), ("key_len", C.c_size_t), ("key_type", C.c_uint32), ("external_input_null", C.c_uint32),
+    ]
+
+
+class EmailRefs:
+    """An array of zke_email_ref over a list of Email values, pointing INTO their bytes objects (nothing is copied; the list is
+    kept alive by this object)."""
+
+    def __init__(self, emails: Sequence["Email"]):
+        self.n = len(emails)
+        self.arr = (zke_email_ref * max(self.n, 1))()
+        self._keep = []
+        ptr = lambda b: C.cast(C.c_char_p(b), C.c_void_p).value if b else None
+        for i, e in enumerate(emails):
+            raw, dom, key = bytes(e.raw_email), e.from_domain.encode("utf-8"), bytes(e.public_key.key)
+            self._keep.append((raw, dom, key))
+            r = self.arr[i]
+            r.raw, r.raw_len, r.from_domain, r.domain_len, r.key, r.key_len = ptr(raw), len(raw), ptr(dom), len(dom), ptr(key), len(key)
+            r.key_type = key_type_code(e.public_key.key_type)
+            r.external_input_null = 1 if any(x.value is None for x in e.external_inputs) else 0
+
+
 class zke_wire_email(C.Structure):
     """View of one decoded borsh / bincode record (zke_wire_decode): pointers into the caller's buffer."""
     _fields_ = [

@@ -87,6 +87,7 @@ struct Slot {
   DevBuf d_image, d_results;
   hipEvent_t host_done = nullptr;      // recorded behind the D2H of the records
   hipEvent_t h2d_done = nullptr;       // recorded behind the slot's input image on the engine's copy stream
+  std::vector<CopyPool::Piece> gather; // zke_verify_emails: the 3 n pieces of the batch being packed (kept: no allocation per call)
   uint64_t host_gen = 0;               // host batches submitted to this slot
   uint64_t host_retired = 0;           // ... of which this many have been delivered to their caller's `out`
   zke_result* host_out = nullptr;      // where the pending batch's records go

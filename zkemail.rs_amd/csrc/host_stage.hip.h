@@ -48,14 +48,20 @@ __attribute__((target("avx2"))) inline void stream_copy_avx2(uint8_t* dst, const
   _mm_sfence();
   if (i < n) memcpy(dst + i, src + i, n - i);
 }
-inline void stage_copy(void* dst, const void* src, size_t n) {
+inline void stage_copy(void* dst, const void* src, size_t n, size_t stream_from = 64u << 10) {
   static const bool avx2 = __builtin_cpu_supports("avx2");
-  if (avx2 && n >= (64u << 10)) stream_copy_avx2((uint8_t*)dst, (const uint8_t*)src, n);
+  if (avx2 && n >= stream_from) stream_copy_avx2((uint8_t*)dst, (const uint8_t*)src, n);
   else memcpy(dst, src, n);
 }
 
 // A handful of threads that do nothing but memcpy.  Several callers may use the pool at once (each call waits for its own
 // pieces only); with one thread configured, or for small copies, the caller's thread does the work itself.
+#ifndef ZKE_GATHER_STREAM_FROM
+#define ZKE_GATHER_STREAM_FROM 1024
+#endif
+#ifndef ZKE_GATHER_CHUNK
+#define ZKE_GATHER_CHUNK (256u << 10)
+#endif
 class CopyPool {
  public:
   explicit CopyPool(unsigned workers) {
@@ -87,12 +93,43 @@ class CopyPool {
       for (const Piece& p : work) stage_copy(p.dst, p.src, p.n);
       return;
     }
+    std::vector<Task> tasks;
+    tasks.reserve(work.size());
+    for (const Piece& p : work) tasks.push_back(Task{&p, 1, 64u << 10, nullptr});
+    run_job(tasks);
+  }
+  // Many small pieces whose destinations follow each other (the e-mails of a batch handed over one by one, each in its own
+  // buffer: `&[Email]` as the reference holds it): consecutive pieces are grouped into tasks of ~256 KB, so a thread is handed a
+  // run of e-mails, not one; pieces of a kilobyte and more go through streaming stores.
+  void gather(const Piece* pieces, size_t count) {
+    constexpr size_t CHUNK = 256 << 10;
+    size_t total = 0;
+    for (size_t i = 0; i < count; i++) total += pieces[i].n;
+    if (threads_.empty() || total < 2 * CHUNK) {
+      for (size_t i = 0; i < count; i++) if (pieces[i].n) stage_copy(pieces[i].dst, pieces[i].src, pieces[i].n, ZKE_GATHER_STREAM_FROM);
+      return;
+    }
+    std::vector<Task> tasks;
+    size_t first = 0, bytes = 0;
+    for (size_t i = 0; i < count; i++) {
+      bytes += pieces[i].n;
+      if (bytes >= ZKE_GATHER_CHUNK || i + 1 == count) { tasks.push_back(Task{pieces + first, i + 1 - first, ZKE_GATHER_STREAM_FROM, nullptr}); first = i + 1; bytes = 0; }
+    }
+    run_job(tasks);
+  }
+
+ private:
+  struct Job { std::mutex mu; std::condition_variable cv; size_t left = 0; };
+  struct Task { const Piece* p; size_t cnt; size_t stream_from; Job* job; };
+  // hand the tasks to the pool, work along, return when all of them are done (`tasks` and what they point to outlive the call)
+  void run_job(std::vector<Task>& tasks) {
+    if (tasks.empty()) return;
     Job job;
-    job.left = work.size();
+    job.left = tasks.size();
     {
       std::lock_guard<std::mutex> g(mu_);
-      for (const Piece& p : work) queue_.push_back(Task{p, &job});
-      pending_.fetch_add((int)work.size(), std::memory_order_release);
+      for (Task& t : tasks) { t.job = &job; queue_.push_back(t); }
+      pending_.fetch_add((int)tasks.size(), std::memory_order_release);
     }
     cv_.notify_all();
     // the caller works too: it takes tasks until the queue is empty, then waits for the stragglers
@@ -108,12 +145,8 @@ class CopyPool {
     std::unique_lock<std::mutex> lk(job.mu);
     job.cv.wait(lk, [&] { return job.left == 0; });
   }
-
- private:
-  struct Job { std::mutex mu; std::condition_variable cv; size_t left = 0; };
-  struct Task { Piece p; Job* job; };
   void do_task(const Task& t) {
-    stage_copy(t.p.dst, t.p.src, t.p.n);
+    for (size_t i = 0; i < t.cnt; i++) if (t.p[i].n) stage_copy(t.p[i].dst, t.p[i].src, t.p[i].n, t.stream_from);
     std::lock_guard<std::mutex> g(t.job->mu);
     if (--t.job->left == 0) t.job->cv.notify_all();
   }

@@ -297,11 +297,17 @@ int retire_host(zke_engine* e, Slot& w) {
   return 0;
 }
 
+// Sizes of a batch handed over as separate e-mails (zke_verify_emails): summed once, by the entry point
+struct RefTotals { uint64_t raw = 0, dom = 0, key = 0; };
+
 // One host-memory batch into slot w (caller holds its lock): pack -> one H2D -> the launches -> one D2H -> event.
-int submit_host(zke_engine* e, Slot& w, const zke_batch* in, zke_result* out, bool want_em, bool want_clean) {
+// refs != nullptr: the e-mails come one by one (zke_email_ref); `in` then carries n only and the offsets are made here.
+int submit_host(zke_engine* e, Slot& w, const zke_batch* in, zke_result* out, bool want_em, bool want_clean,
+                const zke_email_ref* refs = nullptr, const RefTotals* rt = nullptr) {
   const uint32_t n = in->n;
-  const uint64_t raw_total = in->raw_off[n] - in->raw_off[0], dom_total = in->domain_off[n] - in->domain_off[0],
-                 key_total = in->key_off[n] - in->key_off[0];
+  const uint64_t raw_total = refs ? rt->raw : in->raw_off[n] - in->raw_off[0], dom_total = refs ? rt->dom : in->domain_off[n] - in->domain_off[0],
+                 key_total = refs ? rt->key : in->key_off[n] - in->key_off[0];
+  const uint64_t raw_base = refs ? 0 : in->raw_off[0], dom_base = refs ? 0 : in->domain_off[0], key_base = refs ? 0 : in->key_off[0];
   const uint32_t P = in->with_regex ? in->n_header_parts + in->n_body_parts : 0;
   const bool caps = P && in->cap_off;
   const uint32_t n_caps = caps ? in->cap_off[(size_t)n * P] : 0;
@@ -310,7 +316,27 @@ int submit_host(zke_engine* e, Slot& w, const zke_batch* in, zke_result* out, bo
   if (int r = retire_host(e, w)) return r;           // the pinned buffers are about to be overwritten
   if (int r = ensure_host_buffers(e, w, L.total, n)) return r;      // (a no-op: the entry points have grown every slot's staging)
   uint8_t* hp = w.h_image.as<uint8_t>();
-  {
+  if (refs) {
+    // the CSR arrays are written where they will be read from (prefix sums over the lengths), and every e-mail's three buffers
+    // go to their places in the blobs — the pool takes runs of consecutive e-mails (CopyPool::gather)
+    uint64_t* ro = reinterpret_cast<uint64_t*>(hp + L.raw_off), *dofs = reinterpret_cast<uint64_t*>(hp + L.dom_off), *ko = reinterpret_cast<uint64_t*>(hp + L.key_off);
+    uint8_t* kt = hp + L.key_type, *xn = hp + L.ext_null;
+    w.gather.resize((size_t)3 * n);
+    uint64_t r = 0, d = 0, k = 0;
+    for (uint32_t i = 0; i < n; i++) {
+      const zke_email_ref& m = refs[i];
+      ro[i] = r; dofs[i] = d; ko[i] = k;
+      kt[i] = (uint8_t)(m.key_type > ZKE_KEY_OTHER ? ZKE_KEY_OTHER : m.key_type);
+      xn[i] = m.external_input_null ? 1 : 0;
+      w.gather[3 * (size_t)i] = CopyPool::Piece{hp + L.raw + r, m.raw, m.raw_len};
+      w.gather[3 * (size_t)i + 1] = CopyPool::Piece{hp + L.dom + d, m.from_domain, m.domain_len};
+      w.gather[3 * (size_t)i + 2] = CopyPool::Piece{hp + L.key + k, m.key, m.key_len};
+      r += m.raw_len; d += m.domain_len; k += m.key_len;
+    }
+    ro[n] = r; dofs[n] = d; ko[n] = k;
+    if (e->pool) e->pool->gather(w.gather.data(), w.gather.size());
+    else for (const auto& p : w.gather) if (p.n) stage_copy(p.dst, p.src, p.n, ZKE_GATHER_STREAM_FROM);
+  } else {
     // the offsets are copied as they are (the kernels subtract off[0] themselves and the device pointers below are biased
     // by -off[0]): nothing is rebased, nothing is allocated, every byte is written once
     CopyPool::Piece pc[11] = {
@@ -352,11 +378,11 @@ int submit_host(zke_engine* e, Slot& w, const zke_batch* in, zke_result* out, bo
   dv.raw_off = reinterpret_cast<const uint64_t*>(dp + L.raw_off);
   dv.domain_off = reinterpret_cast<const uint64_t*>(dp + L.dom_off);
   dv.key_off = reinterpret_cast<const uint64_t*>(dp + L.key_off);
-  dv.raw_blob = dp + L.raw - in->raw_off[0];
-  dv.domain_blob = dp + L.dom - in->domain_off[0];
-  dv.key_blob = dp + L.key - in->key_off[0];
+  dv.raw_blob = dp + L.raw - raw_base;
+  dv.domain_blob = dp + L.dom - dom_base;
+  dv.key_blob = dp + L.key - key_base;
   dv.key_type = dp + L.key_type;
-  dv.ext_null = in->ext_null ? dp + L.ext_null : nullptr;
+  dv.ext_null = (refs || in->ext_null) ? dp + L.ext_null : nullptr;
   dv.cap_off = caps ? reinterpret_cast<const uint32_t*>(dp + L.cap_off) : nullptr;
   dv.cap_str_off = caps ? reinterpret_cast<const uint32_t*>(dp + L.cap_str_off) : nullptr;
   dv.cap_blob = caps ? dp + L.cap_blob : nullptr;
@@ -747,6 +773,37 @@ int zke_batch_wait(zke_engine* e, uint64_t ticket) {
   if ((ticket >> 6) <= w.host_retired) return 0;        // delivered already (waited for before, or retired by the slot's next batch)
   HIPCHK(e, hipSetDevice(e->device));
   return retire_host(e, w);
+}
+
+int zke_verify_emails_async(zke_engine* e, const zke_email_ref* emails, uint32_t n, zke_result* out, uint64_t* ticket) {
+  if (!e) return ZKE_E_ARG;
+  if (!ticket || (n && (!emails || !out))) return fail(e, ZKE_E_ARG, "zke_verify_emails_async: null pointer");
+  RefTotals t;
+  for (uint32_t i = 0; i < n; i++) {
+    const zke_email_ref& m = emails[i];
+    if ((m.raw_len && !m.raw) || (m.domain_len && !m.from_domain) || (m.key_len && !m.key)) return fail(e, ZKE_E_ARG, "zke_verify_emails_async: null buffer with a length");
+    if (m.raw_len > (1ull << 40) || m.domain_len > (1ull << 32) || m.key_len > (1ull << 32)) return fail(e, ZKE_E_ARG, "zke_verify_emails_async: implausible length");
+    t.raw += m.raw_len; t.dom += m.domain_len; t.key += m.key_len;
+  }
+  if (t.raw > (1ull << 40)) return fail(e, ZKE_E_ARG, "raw e-mails beyond 1 TiB");
+  zke_batch proto{};
+  proto.n = n;
+  if (n) { const size_t img = image_layout(n, t.raw, t.dom, t.key, 0, 0, 0).total; if (img > e->host_image_cap.load() || n > e->host_n_cap.load()) if (int r = grow_host_staging(e, img, n)) return r; }
+  std::shared_lock<std::shared_mutex> sh(e->big);
+  HIPCHK(e, hipSetDevice(e->device));
+  uint32_t slot;
+  Slot& w = next_slot(e, slot);
+  std::lock_guard<std::mutex> g(w.mu);
+  if (n == 0) { *ticket = make_ticket(slot, w.host_retired); return 0; }
+  if (int r = submit_host(e, w, &proto, out, false, false, emails, &t)) return r;
+  *ticket = make_ticket(slot, w.host_gen);
+  return 0;
+}
+
+int zke_verify_emails(zke_engine* e, const zke_email_ref* emails, uint32_t n, zke_result* out) {
+  uint64_t ticket = 0;
+  if (int r = zke_verify_emails_async(e, emails, n, out, &ticket)) return r;
+  return n ? zke_batch_wait(e, ticket) : 0;
 }
 
 int zke_verify_batch(zke_engine* e, const zke_batch* in, zke_result* out, zke_debug_out* dbg) {

@@ -60,6 +60,12 @@ def load_library(path: Optional[str] = None):
     lib.zke_verify_batch_async.restype = C.c_int
     lib.zke_batch_wait.argtypes = [vp, C.c_uint64]
     lib.zke_batch_wait.restype = C.c_int
+    lib.zke_verify_emails.argtypes = [vp, C.POINTER(A.zke_email_ref), C.c_uint32, vp]
+    lib.zke_verify_emails.restype = C.c_int
+    lib.zke_verify_emails_async.argtypes = [vp, C.POINTER(A.zke_email_ref), C.c_uint32, vp, C.POINTER(C.c_uint64)]
+    lib.zke_verify_emails_async.restype = C.c_int
+    lib.zke_status_name.argtypes = [C.c_uint32]
+    lib.zke_status_name.restype = C.c_char_p
     lib.zke_dfa_status.argtypes = [vp, C.c_uint32, u32p]
     lib.zke_dfa_status.restype = C.c_int
     lib.zke_dfa_unregister.argtypes = [vp, C.c_uint32]
@@ -128,7 +134,7 @@ EXPORTED_SYMBOLS = [
     "zke_ed25519_verify_batch", "zke_engine_reserve", "zke_get_slot_timings", "zke_verify_email_with_regex",
     "zke_abi_encode", "zke_engine_join", "zke_verify_batch_async", "zke_batch_wait", "zke_dfa_status", "zke_dfa_unregister",
     "zke_process_init", "zke_abi_version", "zke_engine_reserve_host", "zke_wire_decode", "zke_wire_free", "zke_wire_view",
-    "zke_wire_external_input", "zke_verify_wire", "zke_shard_bounds", "zke_status_name",
+    "zke_wire_external_input", "zke_verify_wire", "zke_shard_bounds", "zke_status_name", "zke_verify_emails", "zke_verify_emails_async",
 ]
 
 
@@ -320,6 +326,21 @@ class Engine:
         ext = 1 if any(x.value is None for x in email.external_inputs) else 0
         return (raw, key), [raw.ctypes.data, len(email.raw_email), dom, len(dom), key.ctypes.data, len(email.public_key.key),
                             A.key_type_code(email.public_key.key_type), ext]
+
+    def verify_emails(self, emails) -> np.ndarray:
+        """zke_verify_emails: a list of Email values (or a prepared ``_abi.EmailRefs``), each with its own buffers, gathered by the
+        engine — no concatenation on the caller's side.  Returns the records."""
+        refs = emails if isinstance(emails, A.EmailRefs) else A.EmailRefs(emails)
+        out = np.zeros(max(refs.n, 1), dtype=A.RESULT_DTYPE)
+        self._check(self.lib.zke_verify_emails(self.h, refs.arr, refs.n, out.ctypes.data), "zke_verify_emails")
+        return out[:refs.n]
+
+    def verify_emails_async(self, refs: "A.EmailRefs"):
+        """zke_verify_emails_async: (ticket, records); the records are valid once ``wait(ticket)`` has returned."""
+        out = np.zeros(max(refs.n, 1), dtype=A.RESULT_DTYPE)
+        t = C.c_uint64()
+        self._check(self.lib.zke_verify_emails_async(self.h, refs.arr, refs.n, out.ctypes.data, C.byref(t)), "zke_verify_emails_async")
+        return t.value, out[:refs.n]
 
     def verify_email(self, email: Email) -> EmailVerifierOutput:
         """core/src/circuits.rs:9-29, through the single-e-mail C entry point zke_verify_email."""
