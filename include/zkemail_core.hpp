@@ -131,6 +131,23 @@ class Engine {
     return out;
   }
 
+  // verify_email over a vector of e-mails, each where it is (zke_verify_emails: the engine gathers the buffers itself):
+  // one record per e-mail, never a throw for a bad e-mail — `status` / `detail` say what the reference would have done.
+  std::vector<zke_result> verify_emails(const std::vector<Email>& emails) {
+    std::vector<zke_email_ref> refs(emails.size());
+    for (size_t i = 0; i < emails.size(); i++) {
+      const Email& em = emails[i];
+      uint32_t ext = 0;
+      for (const auto& x : em.external_inputs) if (!x.value) ext = 1;                    // circuits.rs:24
+      refs[i] = zke_email_ref{em.raw_email.data(), em.raw_email.size(), em.from_domain.data(), em.from_domain.size(),
+                              em.public_key.key.data(), em.public_key.key.size(), key_type_code(em.public_key.key_type), ext};
+    }
+    std::vector<zke_result> out(emails.size());
+    if (int r = zke_verify_emails(e_, refs.data(), (uint32_t)refs.size(), out.data()))
+      throw EngineError("zke_verify_emails failed: " + std::to_string(r) + " " + zke_last_error(e_));
+    return out;
+  }
+
  private:
   static uint32_t key_type_code(const std::string& t) {
     return t == "rsa" ? ZKE_KEY_RSA : (t == "ed25519" ? ZKE_KEY_ED25519 : ZKE_KEY_OTHER);

@@ -3,6 +3,7 @@
 // prints "OK <from_domain_hash hex> <public_key_hash hex> [matches...]" or "PANIC <status> <detail>", and on success a
 // second line "ABI <hex>": VerificationOutput::from_parts(..).abi_encode() (core/src/io.rs:28-44)
 #include <cstdio>
+#include <cstring>
 #include <fstream>
 #include <iterator>
 
@@ -36,6 +37,14 @@ int main(int argc, char** argv) {
       std::printf("OK "); hex(out.from_domain_hash); std::printf(" "); hex(out.public_key_hash); std::printf("\nABI ");
       hex(zkemail::VerificationOutput::from_parts(out, std::nullopt).abi_encode());
       std::printf("\n");
+      // the same e-mail three times and once with its last body byte changed, as a vector of Email values (zke_verify_emails)
+      std::vector<zkemail::Email> many{em, em, em, em};
+      many[2].raw_email.back() ^= 1;
+      zkemail::Engine eng;
+      const auto recs = eng.verify_emails(many);
+      std::printf("BATCH");
+      for (const auto& r : recs) std::printf(" %u/%u", r.status, r.detail);
+      std::printf(" %d\n", (int)(std::memcmp(recs[0].public_key_hash, out.public_key_hash.data(), 32) == 0));
     }
   } catch (const zkemail::VerifyPanic& p) {
     std::printf("PANIC %u %u\n", p.status, p.detail);

@@ -33,6 +33,7 @@ def test_cpp_verify_email_and_panic(tmp_path):
     from zkemail_rs_amd import abi_encode as ae
     from zkemail_rs_amd._abi import EmailVerifierOutput
     assert lines[1] == "ABI " + ae.abi_encode(EmailVerifierOutput(bytes.fromhex(fd), bytes.fromhex(pk), [])).hex()
+    assert lines[2] == "BATCH 0/0 0/0 4/11 0/0 1"     # Engine::verify_emails (zke_verify_emails): the third e-mail's body was changed
     rc_, out = run(tmp_path, cs["fail_body_flipped"])
     assert rc_ == 1 and out == "PANIC 4 11"          # circuits.rs:13, body hash did not verify
 
