@@ -328,9 +328,9 @@ int submit_host(zke_engine* e, Slot& w, const zke_batch* in, zke_result* out, bo
       ro[i] = r; dofs[i] = d; ko[i] = k;
       kt[i] = (uint8_t)(m.key_type > ZKE_KEY_OTHER ? ZKE_KEY_OTHER : m.key_type);
       xn[i] = m.external_input_null ? 1 : 0;
-      w.gather[3 * (size_t)i] = CopyPool::Piece{hp + L.raw + r, m.raw, m.raw_len};
-      w.gather[3 * (size_t)i + 1] = CopyPool::Piece{hp + L.dom + d, m.from_domain, m.domain_len};
-      w.gather[3 * (size_t)i + 2] = CopyPool::Piece{hp + L.key + k, m.key, m.key_len};
+      w.gather[i] = CopyPool::Piece{hp + L.raw + r, m.raw, m.raw_len};                       // three runs, each contiguous in the image
+      w.gather[(size_t)n + i] = CopyPool::Piece{hp + L.dom + d, m.from_domain, m.domain_len};
+      w.gather[2 * (size_t)n + i] = CopyPool::Piece{hp + L.key + k, m.key, m.key_len};
       r += m.raw_len; d += m.domain_len; k += m.key_len;
     }
     ro[n] = r; dofs[n] = d; ko[n] = k;
