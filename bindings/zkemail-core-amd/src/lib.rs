@@ -81,6 +81,20 @@ impl fmt::Display for EngineError {
 
 impl std::error::Error for EngineError {}
 
+/// One `Email` as the C side sees it: pointers into its own buffers (valid while the `Email` is borrowed).
+fn email_ref(e: &Email) -> sys::zke_email_ref {
+    sys::zke_email_ref {
+        raw: e.raw_email.as_ptr(),
+        raw_len: e.raw_email.len(),
+        from_domain: e.from_domain.as_ptr() as *const std::os::raw::c_char,
+        domain_len: e.from_domain.len(),
+        key: e.public_key.key.as_ptr(),
+        key_len: e.public_key.key.len(),
+        key_type: key_type_code(&e.public_key.key_type) as u32,
+        external_input_null: e.external_inputs.iter().any(|x| x.value.is_none()) as u32,
+    }
+}
+
 fn key_type_code(key_type: &str) -> u8 {
     match key_type {
         "rsa" => sys::ZKE_KEY_RSA as u8,
@@ -89,8 +103,10 @@ fn key_type_code(key_type: &str) -> u8 {
     }
 }
 
-/// Struct-of-arrays image of `&[Email]` as `zke_batch` wants it (CSR blobs, `include/zkemail_amd.h`).
-struct Packed {
+/// Struct-of-arrays image of `&[Email]` as `zke_batch` wants it (CSR blobs, `include/zkemail_amd.h`).  `verify_emails` does not
+/// need it (the engine gathers the e-mails from where they are); it is for a caller that submits the same batch more than once
+/// or uploads it to HBM for `zke_verify_batch_device` (`Engine::verify_packed`).
+pub struct Packed {
     raw_blob: Vec<u8>,
     raw_off: Vec<u64>,
     domain_blob: Vec<u8>,
@@ -102,7 +118,7 @@ struct Packed {
 }
 
 impl Packed {
-    fn from_emails<'a, I: Iterator<Item = &'a Email>>(emails: I) -> Self {
+    pub fn from_emails<'a, I: Iterator<Item = &'a Email>>(emails: I) -> Self {
         let mut p = Packed {
             raw_blob: Vec::new(),
             raw_off: vec![0],
@@ -133,7 +149,7 @@ impl Packed {
         p
     }
 
-    fn batch(&self, n: usize) -> sys::zke_batch {
+    pub fn batch(&self, n: usize) -> sys::zke_batch {
         sys::zke_batch {
             n: n as u32,
             raw_blob: self.raw_blob.as_ptr(),
@@ -279,6 +295,18 @@ impl Engine {
         Ok(())
     }
 
+    /// The raw records of a batch packed beforehand (`Packed::from_emails`): `zke_verify_batch` over the three CSR blobs.
+    pub fn verify_packed(&self, packed: &Packed, n: usize) -> Result<Vec<sys::zke_result>, EngineError> {
+        let batch = packed.batch(n);
+        let mut out = vec![zeroed_result(); n];
+        // SAFETY: every pointer in `batch` refers into `packed`, borrowed for the whole (synchronous) call; `out` holds n records.
+        let rc = unsafe { sys::zke_verify_batch(self.raw, &batch, out.as_mut_ptr(), ptr::null_mut()) };
+        if rc != 0 {
+            return Err(self.last_error(rc));
+        }
+        Ok(out)
+    }
+
     /// `verify_email` over a slice: one `Result` per e-mail, in order.  Never aborts the batch on a bad e-mail.
     pub fn verify_emails(&self, emails: &[Email]) -> Result<Vec<Result<EmailVerifierOutput, Panic>>, EngineError> {
         if emails.is_empty() {
@@ -286,19 +314,7 @@ impl Engine {
         }
         // The e-mails stay where they are: one zke_email_ref per `Email`, pointing into its own Vec<u8> / Strings.  The engine
         // gathers them into its pinned staging image on its packing threads (zke_verify_emails) — no concatenation here.
-        let refs: Vec<sys::zke_email_ref> = emails
-            .iter()
-            .map(|e| sys::zke_email_ref {
-                raw: e.raw_email.as_ptr(),
-                raw_len: e.raw_email.len(),
-                from_domain: e.from_domain.as_ptr() as *const std::os::raw::c_char,
-                domain_len: e.from_domain.len(),
-                key: e.public_key.key.as_ptr(),
-                key_len: e.public_key.key.len(),
-                key_type: key_type_code(&e.public_key.key_type) as u32,
-                external_input_null: e.external_inputs.iter().any(|x| x.value.is_none()) as u32,
-            })
-            .collect();
+        let refs: Vec<sys::zke_email_ref> = emails.iter().map(email_ref).collect();
         let mut out = vec![zeroed_result(); emails.len()];
         // SAFETY: every pointer in `refs` refers into `emails`, borrowed for the whole (synchronous) call; `out` holds n records.
         let rc = unsafe { sys::zke_verify_emails(self.raw, refs.as_ptr(), refs.len() as u32, out.as_mut_ptr()) };
@@ -370,19 +386,20 @@ impl Engine {
         if cap_blob.is_empty() {
             cap_blob.push(0);
         }
-        let packed = Packed::from_emails(inputs.iter().map(|i| &i.email));
-        let mut batch = packed.batch(inputs.len());
-        batch.with_regex = 1;
-        batch.n_header_parts = hdr_ids.len() as u32;
-        batch.n_body_parts = body_ids.len() as u32;
-        batch.header_part_ids = hdr_ids.as_ptr();
-        batch.body_part_ids = body_ids.as_ptr();
-        batch.cap_off = if n_parts > 0 { cap_off.as_ptr() } else { ptr::null() };
-        batch.cap_str_off = cap_str_off.as_ptr();
-        batch.cap_blob = cap_blob.as_ptr();
+        // the e-mails stay in their own buffers (zke_verify_emails_with_regex gathers them); only the small tables are built here
+        let refs: Vec<sys::zke_email_ref> = inputs.iter().map(|i| email_ref(&i.email)).collect();
+        let lists = sys::zke_regex_lists {
+            n_header_parts: hdr_ids.len() as u32,
+            header_part_ids: hdr_ids.as_ptr(),
+            n_body_parts: body_ids.len() as u32,
+            body_part_ids: body_ids.as_ptr(),
+            cap_off: if n_parts > 0 { cap_off.as_ptr() } else { ptr::null() },
+            cap_str_off: cap_str_off.as_ptr(),
+            cap_blob: cap_blob.as_ptr(),
+        };
         let mut out = vec![zeroed_result(); inputs.len()];
         // SAFETY: as in verify_emails; the id lists and the capture tables live until the call returns.
-        let rc = unsafe { sys::zke_verify_batch(self.raw, &batch, out.as_mut_ptr(), ptr::null_mut()) };
+        let rc = unsafe { sys::zke_verify_emails_with_regex(self.raw, refs.as_ptr(), refs.len() as u32, &lists, out.as_mut_ptr()) };
         if rc != 0 {
             return Err(self.last_error(rc));
         }

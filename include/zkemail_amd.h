@@ -349,6 +349,18 @@ typedef struct zke_email_ref {
 } zke_email_ref;
 int zke_verify_emails(zke_engine* e, const zke_email_ref* emails, uint32_t n, zke_result* out);
 int zke_verify_emails_async(zke_engine* e, const zke_email_ref* emails, uint32_t n, zke_result* out, uint64_t* ticket);
+/* ... and verify_email_with_regex over `&[EmailWithRegex]` that share one part list (one regex_config per batch): the e-mails as
+ * above, the part lists and the per-e-mail capture tables exactly as zke_batch has them (host arrays; small). */
+typedef struct zke_regex_lists {
+  uint32_t n_header_parts; const uint32_t* header_part_ids;   /* ids from zke_dfa_register, RegexInfo.header_parts order */
+  uint32_t n_body_parts;   const uint32_t* body_part_ids;
+  const uint32_t* cap_off;         /* [n*P + 1] or NULL: no captures anywhere (as zke_batch.cap_off) */
+  const uint32_t* cap_str_off;     /* [n_strings + 1] */
+  const uint8_t*  cap_blob;
+} zke_regex_lists;
+int zke_verify_emails_with_regex(zke_engine* e, const zke_email_ref* emails, uint32_t n, const zke_regex_lists* lists, zke_result* out);
+int zke_verify_emails_with_regex_async(zke_engine* e, const zke_email_ref* emails, uint32_t n, const zke_regex_lists* lists,
+                                       zke_result* out, uint64_t* ticket);
 
 /* Device-resident batch: every pointer in `in` and `out_dev` is device memory (the part-id lists stay host arrays);
  * `raw_total`, `domain_total`, `key_total` are the blob sizes (the CSR tails), which the

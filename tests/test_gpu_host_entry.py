@@ -282,3 +282,23 @@ def test_scattered_emails_entry_equals_the_packed_one(oracle):
         assert_records_equal(eng.verify_emails(refs[0]), want[0], None, "after the refused call")
     finally:
         eng.close()
+
+
+def test_scattered_regex_entry_equals_the_packed_one(oracle):
+    """zke_verify_emails_with_regex: `&[EmailWithRegex]` with the e-mails in their own buffers and the capture tables as
+    zke_batch has them — header and body parts, captures that pass and fail, a batch without any capture string."""
+    import zkemail_rs_amd as z
+    eng = z.Engine(slots=2)
+    try:
+        for cfg in (dict(n=80, body_len=2500, n_header_parts=2, n_body_parts=1, qp_frac=0.05, fail_frac=0.25, seed=31),
+                    dict(n=33, body_len=900, n_header_parts=1, n_body_parts=0, fail_frac=0.3, seed=32)):
+            inputs, wl, _ = synth.make_regex_workload("scat", **cfg)
+            want = eng.verify_batch(eng.pack_with_regex(inputs))
+            assert_records_equal(want, oracle.verify_batch(oracle.pack_with_regex(inputs), threads=4), None, "packed regex entry")
+            assert_records_equal(eng.verify_emails_with_regex(inputs), want, None, f"scattered regex entry {cfg}")
+            if cfg["n_body_parts"]:
+                assert (np.asarray(want["status"]) == 0).sum() > 5 and (np.asarray(want["status"]) != 0).sum() > 5
+        bare = [A.EmailWithRegex(i.email, A.RegexInfo([A.CompiledRegex(p.verify_re, None) for p in i.regex_info.header_parts], None)) for i in inputs]
+        assert_records_equal(eng.verify_emails_with_regex(bare), eng.verify_batch(eng.pack_with_regex(bare)), None, "no capture strings at all")
+    finally:
+        eng.close()

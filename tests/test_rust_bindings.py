@@ -106,13 +106,14 @@ def test_safe_crate_calls_match_the_sys_declarations():
     ext = rust_externs(open(SYS_RS).read())
     calls = [(m.group(1), m.end() - 1) for m in re.finditer(r"sys::(zke_[a-z0-9_]+)\s*\(", src)]
     assert {c for c, _ in calls} >= {"zke_engine_create", "zke_engine_destroy", "zke_verify_batch", "zke_verify_email",
-                                     "zke_verify_email_with_regex", "zke_dfa_register", "zke_engine_reserve", "zke_last_error"}
+                                     "zke_verify_email_with_regex", "zke_dfa_register", "zke_engine_reserve", "zke_last_error",
+                                     "zke_verify_emails", "zke_verify_emails_with_regex"}
     for name, at in calls:
         assert name in ext, name
         assert call_arg_count(src, at) == len(ext[name][0]), (name, call_arg_count(src, at), len(ext[name][0]))
     # struct literals name every field of the sys struct, in any order
     structs = rust_structs(open(SYS_RS).read())
-    for sname in ("zke_batch", "zke_result", "zke_regex_part", "zke_options"):
+    for sname in ("zke_batch", "zke_result", "zke_regex_part", "zke_options", "zke_email_ref", "zke_regex_lists"):
         m = re.search(r"sys::%s \{(.*?)\n\s*\}" % sname, src, flags=re.S)
         assert m, sname
         named = set(re.findall(r"(\w+):", re.sub(r"//.*", "", m.group(1)))) | set(re.findall(r"^\s*(\w+),", m.group(1), flags=re.M))

@@ -163,6 +163,13 @@ class zke_email_ref(C.Structure):
     ]
 
 
+class zke_regex_lists(C.Structure):
+    _fields_ = [
+        ("n_header_parts", C.c_uint32), ("header_part_ids", C.c_void_p), ("n_body_parts", C.c_uint32), ("body_part_ids", C.c_void_p),
+        ("cap_off", C.c_void_p), ("cap_str_off", C.c_void_p), ("cap_blob", C.c_void_p),
+    ]
+
+
 class EmailRefs:
     """An array of zke_email_ref over a list of Email values, pointing INTO their bytes objects (nothing is copied; the list is
     kept alive by this object)."""

@@ -336,6 +336,11 @@ int submit_host(zke_engine* e, Slot& w, const zke_batch* in, zke_result* out, bo
     ro[n] = r; dofs[n] = d; ko[n] = k;
     if (e->pool) e->pool->gather(w.gather.data(), w.gather.size());
     else for (const auto& p : w.gather) if (p.n) stage_copy(p.dst, p.src, p.n, ZKE_GATHER_STREAM_FROM);
+    if (caps) {       // the capture tables of a regex batch arrive in zke_batch's form (small)
+      stage_copy(hp + L.cap_off, in->cap_off, ((size_t)n * P + 1) * 4);
+      stage_copy(hp + L.cap_str_off, in->cap_str_off, ((size_t)n_caps + 1) * 4);
+      if (cap_bytes) stage_copy(hp + L.cap_blob, in->cap_blob, cap_bytes);
+    }
   } else {
     // the offsets are copied as they are (the kernels subtract off[0] themselves and the device pointers below are biased
     // by -off[0]): nothing is rebased, nothing is allocated, every byte is written once
@@ -775,7 +780,8 @@ int zke_batch_wait(zke_engine* e, uint64_t ticket) {
   return retire_host(e, w);
 }
 
-int zke_verify_emails_async(zke_engine* e, const zke_email_ref* emails, uint32_t n, zke_result* out, uint64_t* ticket) {
+int zke_verify_emails_with_regex_async(zke_engine* e, const zke_email_ref* emails, uint32_t n, const zke_regex_lists* lists,
+                                       zke_result* out, uint64_t* ticket) {
   if (!e) return ZKE_E_ARG;
   if (!ticket || (n && (!emails || !out))) return fail(e, ZKE_E_ARG, "zke_verify_emails_async: null pointer");
   RefTotals t;
@@ -788,7 +794,25 @@ int zke_verify_emails_async(zke_engine* e, const zke_email_ref* emails, uint32_t
   if (t.raw > (1ull << 40)) return fail(e, ZKE_E_ARG, "raw e-mails beyond 1 TiB");
   zke_batch proto{};
   proto.n = n;
-  if (n) { const size_t img = image_layout(n, t.raw, t.dom, t.key, 0, 0, 0).total; if (img > e->host_image_cap.load() || n > e->host_n_cap.load()) if (int r = grow_host_staging(e, img, n)) return r; }
+  size_t cap_words = 0, cap_strs = 0, cap_bytes = 0;
+  if (lists) {
+    proto.with_regex = 1;
+    proto.n_header_parts = lists->n_header_parts; proto.header_part_ids = lists->header_part_ids;
+    proto.n_body_parts = lists->n_body_parts; proto.body_part_ids = lists->body_part_ids;
+    proto.cap_off = lists->cap_off; proto.cap_str_off = lists->cap_str_off; proto.cap_blob = lists->cap_blob;
+    if ((proto.n_header_parts && !proto.header_part_ids) || (proto.n_body_parts && !proto.body_part_ids)) return fail(e, ZKE_E_ARG, "part-id list is null");
+    const size_t NP = (size_t)n * ((size_t)proto.n_header_parts + proto.n_body_parts);
+    if (NP && proto.cap_off) {
+      auto rising = [](const uint32_t* off, size_t cnt) { uint32_t bad = 0; for (size_t i = 0; i < cnt; i++) bad |= (uint32_t)(off[i + 1] < off[i]); return !bad; };
+      if (!rising(proto.cap_off, NP) || (proto.cap_off[NP] && (!proto.cap_str_off || !proto.cap_blob || !rising(proto.cap_str_off, proto.cap_off[NP]))))
+        return fail(e, ZKE_E_ARG, "capture offset array is not non-decreasing");
+      if (proto.cap_off[NP] == 0) proto.cap_off = nullptr;            // tables without a single string: the same as no tables
+      else { cap_words = NP + 1; cap_strs = (size_t)proto.cap_off[NP] + 1; cap_bytes = proto.cap_str_off[proto.cap_off[NP]]; }
+    } else {
+      proto.cap_off = nullptr;
+    }
+  }
+  if (n) { const size_t img = image_layout(n, t.raw, t.dom, t.key, cap_words, cap_strs, cap_bytes).total; if (img > e->host_image_cap.load() || n > e->host_n_cap.load()) if (int r = grow_host_staging(e, img, n)) return r; }
   std::shared_lock<std::shared_mutex> sh(e->big);
   HIPCHK(e, hipSetDevice(e->device));
   uint32_t slot;
@@ -800,10 +824,18 @@ int zke_verify_emails_async(zke_engine* e, const zke_email_ref* emails, uint32_t
   return 0;
 }
 
-int zke_verify_emails(zke_engine* e, const zke_email_ref* emails, uint32_t n, zke_result* out) {
+int zke_verify_emails_async(zke_engine* e, const zke_email_ref* emails, uint32_t n, zke_result* out, uint64_t* ticket) {
+  return zke_verify_emails_with_regex_async(e, emails, n, nullptr, out, ticket);
+}
+
+int zke_verify_emails_with_regex(zke_engine* e, const zke_email_ref* emails, uint32_t n, const zke_regex_lists* lists, zke_result* out) {
   uint64_t ticket = 0;
-  if (int r = zke_verify_emails_async(e, emails, n, out, &ticket)) return r;
+  if (int r = zke_verify_emails_with_regex_async(e, emails, n, lists, out, &ticket)) return r;
   return n ? zke_batch_wait(e, ticket) : 0;
+}
+
+int zke_verify_emails(zke_engine* e, const zke_email_ref* emails, uint32_t n, zke_result* out) {
+  return zke_verify_emails_with_regex(e, emails, n, nullptr, out);
 }
 
 int zke_verify_batch(zke_engine* e, const zke_batch* in, zke_result* out, zke_debug_out* dbg) {

@@ -64,6 +64,10 @@ def load_library(path: Optional[str] = None):
     lib.zke_verify_emails.restype = C.c_int
     lib.zke_verify_emails_async.argtypes = [vp, C.POINTER(A.zke_email_ref), C.c_uint32, vp, C.POINTER(C.c_uint64)]
     lib.zke_verify_emails_async.restype = C.c_int
+    lib.zke_verify_emails_with_regex.argtypes = [vp, C.POINTER(A.zke_email_ref), C.c_uint32, C.POINTER(A.zke_regex_lists), vp]
+    lib.zke_verify_emails_with_regex.restype = C.c_int
+    lib.zke_verify_emails_with_regex_async.argtypes = [vp, C.POINTER(A.zke_email_ref), C.c_uint32, C.POINTER(A.zke_regex_lists), vp, C.POINTER(C.c_uint64)]
+    lib.zke_verify_emails_with_regex_async.restype = C.c_int
     lib.zke_status_name.argtypes = [C.c_uint32]
     lib.zke_status_name.restype = C.c_char_p
     lib.zke_dfa_status.argtypes = [vp, C.c_uint32, u32p]
@@ -135,6 +139,7 @@ EXPORTED_SYMBOLS = [
     "zke_abi_encode", "zke_engine_join", "zke_verify_batch_async", "zke_batch_wait", "zke_dfa_status", "zke_dfa_unregister",
     "zke_process_init", "zke_abi_version", "zke_engine_reserve_host", "zke_wire_decode", "zke_wire_free", "zke_wire_view",
     "zke_wire_external_input", "zke_verify_wire", "zke_shard_bounds", "zke_status_name", "zke_verify_emails", "zke_verify_emails_async",
+    "zke_verify_emails_with_regex", "zke_verify_emails_with_regex_async",
 ]
 
 
@@ -333,6 +338,20 @@ class Engine:
         refs = emails if isinstance(emails, A.EmailRefs) else A.EmailRefs(emails)
         out = np.zeros(max(refs.n, 1), dtype=A.RESULT_DTYPE)
         self._check(self.lib.zke_verify_emails(self.h, refs.arr, refs.n, out.ctypes.data), "zke_verify_emails")
+        return out[:refs.n]
+
+    def verify_emails_with_regex(self, inputs: Sequence[EmailWithRegex]) -> np.ndarray:
+        """zke_verify_emails_with_regex: a list of EmailWithRegex that share one part list; the e-mails stay in their own buffers,
+        the part ids and capture tables are built as ``pack_with_regex`` builds them."""
+        p = self.pack_with_regex(inputs)                      # (registers the pairs; only its id lists and capture tables are used)
+        refs = A.EmailRefs([i.email for i in inputs])
+        lists = A.zke_regex_lists()
+        lists.n_header_parts, lists.n_body_parts = p.nh, p.nb
+        lists.header_part_ids, lists.body_part_ids = p.hdr_ids.ctypes.data, p.body_ids.ctypes.data
+        if p.has_caps:
+            lists.cap_off, lists.cap_str_off, lists.cap_blob = p.cap_off.ctypes.data, p.cap_str_off.ctypes.data, p.cap_blob.ctypes.data
+        out = np.zeros(max(refs.n, 1), dtype=A.RESULT_DTYPE)
+        self._check(self.lib.zke_verify_emails_with_regex(self.h, refs.arr, refs.n, C.byref(lists), out.ctypes.data), "zke_verify_emails_with_regex")
         return out[:refs.n]
 
     def verify_emails_async(self, refs: "A.EmailRefs"):
