@@ -74,6 +74,15 @@ def parse_args():
     return ap.parse_args()
 
 
+_T0 = time.time()
+
+
+def stage(msg: str):
+    """Progress on stderr (stdout carries the one JSON line): where the run was, should it die."""
+    sys.stderr.write(f"[bench +{time.time() - _T0:6.1f}s rank {os.environ.get('RANK', '0')}] {msg}\n")
+    sys.stderr.flush()
+
+
 def default_slots(with_communicator: bool) -> int:
     """Submission slots per GPU when --streams is not given: 22 alone, 18 beside an RCCL communicator (main() says why)."""
     return 18 if with_communicator else 22
@@ -215,6 +224,7 @@ def main():
     else:
         wl = synth.make_workload(args.workload, seed=1000 + rank, **cfg)
     gen_s = time.time() - t0
+    stage(f"workload {args.workload} generated in {gen_s:.1f} s")
     S = max(1, min(args.streams, 64))
     # ONE engine per GPU with S submission slots (a stream and a workspace each; the key cache, the DFA tables and the
     # kernel attributes exist once).  S batches are in flight: a step is still one batch of n e-mails, consecutive steps
@@ -232,8 +242,10 @@ def main():
     n = packed.n
     P = (packed.nh + packed.nb) if regex_inputs is not None else 0
     eng.reserve(n, totals[0], S, P)
+    stage(f"engine ready: {S} slots")
     if use_dist:
         init_pg()
+        stage("process group up")
     # Result records.  One GPU: a slice per batch in flight.  N > 1: every timed step keeps its records (one slice per
     # step) and the ranks exchange them with ONE all-gather at the end of the timed region — SURVEY §8(e): "one exchange
     # step at the end".  (Measured alternatives on this box, forced through RCCL at N = 1: an all-gather inside every
@@ -307,6 +319,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     gc.enable()
+    stage(f"timed region done: {args.steps} steps in {dt * 1e3:.2f} ms")
     if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -333,6 +346,7 @@ def main():
         mine = gathered_all[rank * g_steps * wit_bytes:(rank + 1) * g_steps * wit_bytes]
         assert bool((mine == D.witness_tensor(results_all[:g_steps * rec_bytes])).all().item())
 
+    stage("records of the timed steps checked")
     # ---- per-kernel device time, HIP events on the stream each kernel is launched on
     # (a) IN FLIGHT: the timed region's own mode — S batches in flight, events recorded between the kernels of every
     #     batch, read from each slot once everything has drained (the last batch of each slot).  Not inside the timed
@@ -356,6 +370,7 @@ def main():
             rows.append(eng.timings())
         kern_alone = avg_timings(rows)
     eng.set_timing(False)
+    stage("per-kernel timings read (in flight, alone)")
 
     emails_per_s = world * n * args.steps / dt
     # The SHA-256 body kernel's algorithmic bytes, SURVEY §8(d): every canonical body byte read once + 32 B written per e-mail ...
@@ -486,10 +501,11 @@ def main():
     # ---- end to end: the same workload from pageable host memory (what a drop-in caller holds: core/src/circuits.rs:9 takes a
     # RAM-resident &Email), zke_verify_batch_async through every slot, H2D and D2H inside the clock; and the latency of ONE call
     orc = None
-    if rank == 0 and world == 1 and not args.no_cpu:
+    if rank == 0 and world == 1 and not use_dist and not args.no_cpu:
         import oracle_lib
         orc = oracle_lib.load()
-    if rank == 0 and world == 1 and not args.no_e2e:
+    if rank == 0 and world == 1 and not use_dist and not args.no_e2e:       # (not beside a communicator: the N > 1 path has no such leg,
+                                                                            # and its one-rank rehearsal is that path, nothing more)
         # An engine of its own for the host entry: 16 slots.  Its input copies run on two copy streams, and slots + copy streams
         # + the null stream must stay within the hardware queues a process gets (23): 22 slots beside them share queues (150 us
         # per batch against 120 with 16 or 12 slots; the device is not the limit here, the link and the host's packing are).
@@ -502,7 +518,9 @@ def main():
         if regex_inputs is not None:
             packed = eng.pack_with_regex(regex_inputs)
         eng.reserve(n, totals[0], S_host, P)
+        stage("end-to-end leg (host entry, a 16-slot engine of its own)")
         out["end_to_end"] = end_to_end_leg(torch, dev, eng, packed, n, S_host, totals, wl)
+        stage("latency leg")
         out["single_email_latency_us"] = latency_leg(eng, packed, wl, regex_inputs, orc)
 
     # ---- CPU baseline: the oracle (port) on this box's host cores, rank 0, N = 1 only
@@ -532,8 +550,10 @@ def main():
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
+    stage("line written")
     if use_dist:
         dist.destroy_process_group()
+        stage("process group down")
 
 
 def cpu_model() -> str:
