@@ -552,6 +552,9 @@ def main():
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     stage("line written")
     if use_dist:
+        torch.cuda.synchronize()          # nothing of this rank is in flight, and every rank has got here, before the communicator goes
+        dist.barrier()
+        torch.cuda.synchronize()
         dist.destroy_process_group()
         stage("process group down")
 
@@ -812,6 +815,9 @@ def strong_scaling_main(args, cfgs, rank, local_rank, world, json_fd):
                "hashed_body_GBps": round(wl.body_bytes * args.steps / dt / 1e9, 3), "workload_gen_s": round(gen_s, 2)}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
         dist.destroy_process_group()
 
 
