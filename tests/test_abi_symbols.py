@@ -99,3 +99,28 @@ def test_null_arguments_are_refused_not_dereferenced():
     assert lib.zke_dfa_status(None, 0, C.byref(u)) == E_ARG and lib.zke_dfa_unregister(None, 0) == E_ARG
     assert isinstance(lib.zke_last_error(None), bytes)        # the calling thread's last failure message, "" if none
     assert lib.zke_abi_version() == 3
+
+
+def test_email_refs_point_into_the_emails_own_buffers():
+    """_abi.EmailRefs (zke_verify_emails): one zke_email_ref per Email, pointers into its bytes objects, nothing copied; and the
+    entry points refuse null arrays before anything touches a GPU."""
+    from zkemail_rs_amd._abi import Email, EmailRefs, ExternalInput, PublicKey, zke_email_ref
+    assert C.sizeof(zke_email_ref) == 56
+    ems = [Email("example.com", b"From: a@example.com\r\n\r\nbody\r\n", PublicKey(b"\x30\x03\x02\x01\x03", "rsa")),
+           Email("", b"", PublicKey(b"", "ed25519"), [ExternalInput("x", None, 1)]),
+           Email("exämple.org", b"\x00\xff" * 40, PublicKey(bytes(range(32)), "dsa"))]
+    refs = EmailRefs(ems)
+    assert refs.n == 3
+    for r, e in zip(refs.arr, ems):
+        dom = e.from_domain.encode("utf-8")
+        assert (r.raw_len, r.domain_len, r.key_len) == (len(e.raw_email), len(dom), len(e.public_key.key))
+        assert C.string_at(r.raw, r.raw_len) == e.raw_email if r.raw_len else r.raw is None
+        assert C.string_at(r.from_domain, r.domain_len) == dom if r.domain_len else r.from_domain is None
+        assert C.string_at(r.key, r.key_len) == e.public_key.key if r.key_len else r.key is None
+    assert [r.key_type for r in refs.arr[:3]] == [0, 1, 2] and [r.external_input_null for r in refs.arr[:3]] == [0, 1, 0]
+    lib = engine.load_library()
+    t = C.c_uint64()
+    E_ARG = -1
+    assert lib.zke_verify_emails(None, refs.arr, 3, None) == E_ARG
+    assert lib.zke_verify_emails_async(None, None, 0, None, C.byref(t)) == E_ARG
+    assert lib.zke_verify_emails_with_regex(None, refs.arr, 3, None, None) == E_ARG
