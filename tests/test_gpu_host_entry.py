@@ -302,3 +302,39 @@ def test_scattered_regex_entry_equals_the_packed_one(oracle):
         assert_records_equal(eng.verify_emails_with_regex(bare), eng.verify_batch(eng.pack_with_regex(bare)), None, "no capture strings at all")
     finally:
         eng.close()
+
+
+def test_engine_lifecycle_returns_its_memory(oracle):
+    """40 engines created, used (host entry, gathering entry, a regex batch, the device-mode reserve) and destroyed one after
+    the other: device memory free after the last is what it was after the first (no workspace, staging image, DFA table or key
+    cache left behind), and every one of them answers like the first."""
+    import ctypes as C
+    import zkemail_rs_amd as z
+    hip = C.CDLL("libamdhip64.so")
+    free, total = C.c_size_t(), C.c_size_t()
+
+    def free_now():
+        assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+        return free.value
+    (p, wl) = _batches(1, n=200, seed0=800)[0]
+    inputs, _, _ = synth.make_regex_workload("life", 40, 1500, n_header_parts=1, n_body_parts=1, qp_frac=0.05, seed=801)
+    want = want_rx = None
+    after_first = None
+    for k in range(40):
+        eng = z.Engine(slots=4, host_threads=2)
+        try:
+            eng.reserve(256, 1 << 20, 4, 2)
+            got = eng.verify_batch(p)
+            got2 = eng.verify_emails(list(wl.emails))
+            rx = eng.verify_batch(eng.pack_with_regex(inputs))
+            if want is None:
+                want, want_rx = got.copy(), rx.copy()
+                assert_records_equal(want, oracle.verify_batch(p, threads=4), None, "first engine")
+            assert_records_equal(got, want, None, f"engine {k}")
+            assert_records_equal(got2, want, None, f"engine {k}, gathering entry")
+            assert_records_equal(rx, want_rx, None, f"engine {k}, regex")
+        finally:
+            eng.close()
+        if after_first is None:
+            after_first = free_now()
+    assert abs(free_now() - after_first) <= (64 << 20), (free_now(), after_first)       # (the runtime keeps a few MB of its own)
