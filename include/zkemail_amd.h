@@ -281,6 +281,7 @@ typedef struct zke_timings {
 int zke_process_init(uint32_t hw_queues);
 
 int zke_engine_create(const zke_options* opt, zke_engine** out);
+/* Waits for everything in flight; host batches nobody waited for are delivered to their `out` arrays on the way out. */
 void zke_engine_destroy(zke_engine* e);
 /* The message of the last failed call on this engine by the calling thread ("" if none). */
 const char* zke_last_error(const zke_engine* e);

@@ -338,3 +338,10 @@ def test_engine_lifecycle_returns_its_memory(oracle):
         if after_first is None:
             after_first = free_now()
     assert abs(free_now() - after_first) <= (64 << 20), (free_now(), after_first)       # (the runtime keeps a few MB of its own)
+    # an engine destroyed with batches nobody waited for delivers them on the way out (include/zkemail_amd.h: `out` stays valid
+    # until zke_batch_wait — or zke_engine_destroy — has returned)
+    eng = z.Engine(slots=3)
+    pend = [eng.verify_batch_async(p) for _ in range(3)]
+    eng.close()
+    for _, rec in pend:
+        assert_records_equal(rec, want, None, "delivered by zke_engine_destroy")
