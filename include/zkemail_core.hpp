@@ -148,6 +148,52 @@ class Engine {
     return out;
   }
 
+  // verify_email_with_regex over a vector that shares one part list (one regex_config per batch; the captures are per e-mail):
+  // the pairs are registered once (zke_dfa_register), the e-mails stay where they are (zke_verify_emails_with_regex).
+  std::vector<zke_result> verify_emails_with_regex(const std::vector<EmailWithRegex>& in) {
+    if (in.empty()) return {};
+    std::vector<uint32_t> hids, bids;
+    auto ids_of = [&](const std::optional<std::vector<CompiledRegex>>& parts) {
+      std::vector<uint32_t> v;
+      if (parts)
+        for (const auto& p : *parts) {
+          uint32_t id = 0;
+          if (int r = zke_dfa_register(e_, p.verify_re.fwd.data(), p.verify_re.fwd.size(), p.verify_re.bwd.data(), p.verify_re.bwd.size(), &id))
+            throw EngineError("zke_dfa_register failed: " + std::to_string(r) + " " + zke_last_error(e_));
+          v.push_back(id);                       // an equal pair registered again gets the id it already has
+        }
+      return v;
+    };
+    hids = ids_of(in[0].regex_info.header_parts);
+    bids = ids_of(in[0].regex_info.body_parts);
+    std::vector<zke_email_ref> refs(in.size());
+    std::vector<uint32_t> cap_off{0}, cap_str_off{0};
+    std::vector<uint8_t> cap_blob;
+    for (size_t i = 0; i < in.size(); i++) {
+      const Email& em = in[i].email;
+      if (ids_of(in[i].regex_info.header_parts) != hids || ids_of(in[i].regex_info.body_parts) != bids)
+        throw EngineError("a batch must share one part list; split it per regex_config");
+      uint32_t ext = 0;
+      for (const auto& x : em.external_inputs) if (!x.value) ext = 1;
+      refs[i] = zke_email_ref{em.raw_email.data(), em.raw_email.size(), em.from_domain.data(), em.from_domain.size(),
+                              em.public_key.key.data(), em.public_key.key.size(), key_type_code(em.public_key.key_type), ext};
+      for (const auto* parts : {&in[i].regex_info.header_parts, &in[i].regex_info.body_parts})
+        if (*parts)
+          for (const auto& p : **parts) {
+            if (p.captures)
+              for (const auto& s : *p.captures) { cap_blob.insert(cap_blob.end(), s.begin(), s.end()); cap_str_off.push_back((uint32_t)cap_blob.size()); }
+            cap_off.push_back((uint32_t)cap_str_off.size() - 1);
+          }
+    }
+    if (cap_blob.empty()) cap_blob.push_back(0);
+    zke_regex_lists lists{(uint32_t)hids.size(), hids.data(), (uint32_t)bids.size(), bids.data(),
+                          hids.size() + bids.size() ? cap_off.data() : nullptr, cap_str_off.data(), cap_blob.data()};
+    std::vector<zke_result> out(in.size());
+    if (int r = zke_verify_emails_with_regex(e_, refs.data(), (uint32_t)refs.size(), &lists, out.data()))
+      throw EngineError("zke_verify_emails_with_regex failed: " + std::to_string(r) + " " + zke_last_error(e_));
+    return out;
+  }
+
  private:
   static uint32_t key_type_code(const std::string& t) {
     return t == "rsa" ? ZKE_KEY_RSA : (t == "ed25519" ? ZKE_KEY_ED25519 : ZKE_KEY_OTHER);

@@ -32,6 +32,13 @@ int main(int argc, char** argv) {
       std::printf("\nABI ");
       hex(zkemail::VerificationOutput::from_parts(out.email, out.regex_matches).abi_encode());
       std::printf("\n");
+      // the same input twice and once with a capture the match does not contain, as a vector (zke_verify_emails_with_regex)
+      std::vector<zkemail::EmailWithRegex> many{in, in, in};
+      (*many[1].regex_info.header_parts)[0].captures = std::vector<std::string>{"not-in-the-match"};
+      zkemail::Engine eng;
+      std::printf("BATCH");
+      for (const auto& r : eng.verify_emails_with_regex(many)) std::printf(" %u/%u", r.status, r.detail);
+      std::printf("\n");
     } else {
       auto out = zkemail::verify_email(em);
       std::printf("OK "); hex(out.from_domain_hash); std::printf(" "); hex(out.public_key_hash); std::printf("\nABI ");

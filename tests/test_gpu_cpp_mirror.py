@@ -50,5 +50,6 @@ def test_cpp_verify_email_with_regex(tmp_path):
     from zkemail_rs_amd._abi import EmailVerifierOutput
     fd, pk = (bytes.fromhex(x) for x in lines[0].split()[1:3])
     assert lines[1] == "ABI " + ae.abi_encode(EmailVerifierOutput(fd, pk, []), ["subject:"]).hex()
+    assert lines[2] == "BATCH 0/0 8/61 0/0"          # Engine::verify_emails_with_regex: the second input's capture is not contained
     rc_, out = run(tmp_path, ok, [str(tmp_path / "f.dfa"), str(tmp_path / "b.dfa"), "not-in-the-match"])
     assert rc_ == 1 and out == "PANIC 8 61"          # circuits.rs:45, capture not contained (regex.rs:44)
